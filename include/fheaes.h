@@ -1,0 +1,152 @@
+/*
+ * fheaes.h -- C ABI of the MI355X-native FHE-AES engine (libfheaes.so).
+ *
+ * Drop-in boundary for the WoPBS S-Box hot path of rostin79s/TFHE-AES.  Every entry
+ * point names the reference interface it replaces (paths relative to the reference
+ * repository).  The reference is a pure-Rust crate with no FFI of its own; these are
+ * the symbols a Rust `extern "C"` shim would bind.
+ *
+ * Conventions
+ *   - all ciphertext / key words are uint64_t (torus q = 2^64), little endian, contiguous;
+ *   - LWE ciphertext  = [a_0 .. a_{d-1}, b]                      (d+1 words);
+ *   - GLWE ciphertext = [A_0 | .. | A_{k-1} | B], each N words   ((k+1)N words);
+ *   - an AES byte     = 8 LWE ciphertexts under the big key (d = kN), block j = bit j (LSB first),
+ *                       message bit at the MSB (delta = 2^63, no padding)   (client.rs:123-138);
+ *   - an AES state    = 16 bytes, index = 4*col + row, byte 0 = MSB of the u128;
+ *   - every function returns FHEAES_OK (0) or a negative error code and never unwinds;
+ *     fheaes_last_error() gives the message.  Shape / parameter mismatches are errors;
+ *   - `memspace` says where the data pointers of that call live: FHEAES_HOST (the engine
+ *     stages them through HBM) or FHEAES_DEVICE (HBM pointers, work is enqueued on the
+ *     context's stream and NOT synchronised: call fheaes_synchronize()).
+ *   - per-call pointers are borrowed for the duration of the call; keys are copied into
+ *     HBM by fheaes_upload_keys() and owned by the context (server.rs:32-35 takes keys by value).
+ */
+#ifndef FHEAES_H
+#define FHEAES_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FHEAES_OK 0
+#define FHEAES_ERR_INVALID -1  /* bad argument / shape / parameter set */
+#define FHEAES_ERR_NOKEYS -2   /* evaluation before fheaes_upload_keys */
+#define FHEAES_ERR_DEVICE -3   /* HIP runtime error (message in last_error) */
+#define FHEAES_ERR_NOMEM -4
+
+#define FHEAES_HOST 0
+#define FHEAES_DEVICE 1
+
+/* WopbsParameters of the reference (client.rs:31-57), minus the noise fields that only
+ * key generation needs.  polynomial_size must be 512. */
+typedef struct fheaes_params {
+    uint32_t lwe_dimension;   /* n   = 669 */
+    uint32_t glwe_dimension;  /* k   = 4   */
+    uint32_t polynomial_size; /* N   = 512 */
+    uint32_t pbs_base_log;    /* 8  */
+    uint32_t pbs_level;       /* 5  */
+    uint32_t ks_base_log;     /* 2  */
+    uint32_t ks_level;        /* 6  */
+    uint32_t pfks_base_log;   /* 12 */
+    uint32_t pfks_level;      /* 3  */
+    uint32_t cbs_base_log;    /* 15 */
+    uint32_t cbs_level;       /* 1  */
+} fheaes_params;
+
+typedef struct fheaes_ctx fheaes_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+/* Server::new (server.rs:32): create an engine on HIP device `device`. */
+int fheaes_create(const fheaes_params *params, int device, fheaes_ctx **out);
+void fheaes_destroy(fheaes_ctx *ctx);
+/* message of the last failing call on this context (ctx == NULL: last fheaes_create failure) */
+const char *fheaes_last_error(const fheaes_ctx *ctx);
+
+/* ---- keys ---------------------------------------------------------------------- */
+/* word counts of the three evaluation keys for this parameter set */
+#define FHEAES_KEY_KSK 0    /* [kN][ks_level][n+1]                 pbs_server_key.key_switching_key (many_wopbs.rs:168) */
+#define FHEAES_KEY_BSK 1    /* [n][pbs_level][k+1][k+1][N]  STANDARD domain  wopbs_server_key.bootstrapping_key (many_wopbs.rs:34-35) */
+#define FHEAES_KEY_PFPKSK 2 /* [k+1][kN+1][pfks_level][(k+1)N]     cbs_pfpksk (many_wopbs.rs:76) */
+size_t fheaes_key_words(const fheaes_ctx *ctx, int which);
+
+/* Copies the keys into HBM and converts the BSK to the engine's Fourier layout.
+ * Level index 0 is the most significant level (weight 2^(64-base_log)). */
+int fheaes_upload_keys(fheaes_ctx *ctx, const uint64_t *ksk, const uint64_t *bsk, const uint64_t *pfpksk, int memspace);
+
+/* ---- stream / sync / workspace ------------------------------------------------- */
+int fheaes_set_stream(fheaes_ctx *ctx, void *hip_stream); /* NULL: the context's own stream */
+int fheaes_synchronize(fheaes_ctx *ctx);
+/* pre-size the device workspace for batches of up to `max_bits` one-bit inputs in flight */
+int fheaes_reserve(fheaes_ctx *ctx, uint64_t max_bits);
+
+/* ---- the hot path, stage by stage (what many_wopbs.rs calls into tfhe 0.11.2) --- */
+/* K1  shortint::wopbs::WopbsKey::extract_bits_assign (many_wopbs.rs:194): one LWE keyswitch
+ *     big -> small per bit.  in [m][kN+1] -> out [m][n+1]. */
+int fheaes_keyswitch_batch(fheaes_ctx *ctx, const uint64_t *lwe_in, uint64_t m, uint64_t *lwe_out, int memspace);
+/* K2  the PBS inside circuit_bootstrap_boolean (many_wopbs.rs:253), CBS level `level` (1-based):
+ *     in [m][n+1] -> out [m][kN+1] = LWE of bit * 2^(64 - cbs_base_log*level). */
+int fheaes_cbs_pbs_batch(fheaes_ctx *ctx, const uint64_t *lwe_small, uint64_t m, uint32_t level, uint64_t *lwe_out, int memspace);
+/* K3  the k+1 private functional packing keyswitches of circuit_bootstrap_boolean:
+ *     in [m][kN+1] -> out [m][k+1][(k+1)N]  (one GGSW level, standard domain). */
+int fheaes_pfpks_batch(fheaes_ctx *ctx, const uint64_t *lwe_in, uint64_t m, uint64_t *ggsw_rows_out, int memspace);
+/* K4  ggsw.fill_with_forward_fourier (many_wopbs.rs:263): `polys` torus polynomials -> Fourier,
+ *     out [polys][256][2] doubles (natural order, re/im interleaved). */
+int fheaes_forward_fourier_batch(fheaes_ctx *ctx, const uint64_t *polys_in, uint64_t polys, double *fourier_out, int memspace);
+/* K5  vertical_packing (many_wopbs.rs:277).  ggsw_fourier [n_inputs][bits][cbs_level][k+1][k+1][256][2];
+ *     luts [n_sets][n_luts][bits][N] with n_sets = lut_per_input ? n_inputs : 1;
+ *     out  [n_inputs][n_luts][bits][kN+1]. */
+int fheaes_vertical_packing_batch(fheaes_ctx *ctx, const double *ggsw_fourier, uint64_t n_inputs, uint32_t bits,
+                                  const uint64_t *luts, uint32_t n_luts, int lut_per_input, uint64_t *lwe_out, int memspace);
+
+/* ---- the plugin API of the path ------------------------------------------------ */
+/* many_wopbs_without_padding (many_wopbs.rs:31), batched over radix inputs.
+ *   lwe_in [n_inputs][bits][kN+1], bits in {1..9}; luts as above; out [n_inputs][n_luts][bits][kN+1]. */
+int fheaes_wopbs_batch(fheaes_ctx *ctx, const uint64_t *lwe_in, uint64_t n_inputs, uint32_t bits,
+                       const uint64_t *luts, uint32_t n_luts, int lut_per_input, uint64_t *lwe_out, int memspace);
+/* gen_lut (gen_lut.rs:9) for message_modulus 2, carry_modulus 1: f_table[2^nb_block] -> out [nb_block][N] (host only). */
+int fheaes_gen_lut(uint32_t nb_block, const uint64_t *f_table, uint64_t *lut_out);
+/* sbox (sbox.rs:46), in place over n_bytes bytes: bytes [n_bytes][8][kN+1]; inv = 0 SBOX, 1 INV_SBOX. */
+int fheaes_sbox(fheaes_ctx *ctx, uint64_t *bytes, uint64_t n_bytes, int inv, int memspace);
+/* many_sbox (sbox.rs:68): out [n_bytes][L][8][kN+1], L = 3 {S,2S,3S} (inv=0) or 4 {9x,11x,13x,14x} (inv=1). */
+int fheaes_many_sbox(fheaes_ctx *ctx, const uint64_t *bytes, uint64_t n_bytes, int inv, uint64_t *out, int memspace);
+
+/* ---- Server API (server.rs) ---------------------------------------------------- */
+/* Server::aes_key_expansion (server.rs:107): key [16][8][kN+1] -> round_keys [11][16][8][kN+1]. */
+int fheaes_aes_key_expansion(fheaes_ctx *ctx, const uint64_t *key, uint64_t *round_keys, int memspace);
+/* Server::aes_encrypt (server.rs:39), batched: state [n_blocks][16][8][kN+1] in place, one set of round keys. */
+int fheaes_aes_encrypt(fheaes_ctx *ctx, const uint64_t *round_keys, uint64_t *state, uint64_t n_blocks, int memspace);
+/* Server::aes_decrypt (server.rs:67), batched. */
+int fheaes_aes_decrypt(fheaes_ctx *ctx, const uint64_t *round_keys, uint64_t *state, uint64_t n_blocks, int memspace);
+/* Server::add_scalar (server.rs:172), batched: state[b] += counters[b] (u128 as {hi, lo}, host array
+ * of 2*n_blocks words regardless of memspace).  The first-byte carry uses counter & 0xFF (the
+ * reference's server.rs:182 is wrong for counters >= 256). */
+int fheaes_add_scalar(fheaes_ctx *ctx, uint64_t *state, uint64_t n_blocks, const uint64_t *counters_hi_lo, int memspace);
+
+/* ---- measurement --------------------------------------------------------------- */
+#define FHEAES_STAGE_KEYSWITCH 0
+#define FHEAES_STAGE_BLIND_ROTATE 1
+#define FHEAES_STAGE_PFPKS 2
+#define FHEAES_STAGE_GGSW_FFT 3
+#define FHEAES_STAGE_VERTICAL_PACKING 4
+#define FHEAES_STAGE_LINEAR 5
+#define FHEAES_STAGE_COUNT 6
+/* When enabled every kernel launch is bracketed by HIP events on the launch stream. */
+int fheaes_profile_enable(fheaes_ctx *ctx, int on);
+int fheaes_profile_reset(fheaes_ctx *ctx);
+/* synchronises, then returns accumulated kernel time, launches and units (bits or polys) of a stage */
+int fheaes_profile_read(fheaes_ctx *ctx, int stage, double *total_ms, uint64_t *launches, uint64_t *units);
+
+/* ---- introspection (parity tests) ---------------------------------------------- */
+/* psi^j = exp(i*pi*j/512), j < 512, re/im interleaved: the twiddle table the kernels use */
+int fheaes_get_twiddles(double *psi_out);
+/* Fourier image of GGSW `i` of the uploaded BSK: out [pbs_level][k+1][k+1][256][2] */
+int fheaes_read_bsk_fourier(fheaes_ctx *ctx, uint32_t i, double *out);
+const char *fheaes_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FHEAES_H */

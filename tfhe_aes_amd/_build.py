@@ -1,0 +1,79 @@
+"""In-tree builds of the native libraries (no JIT cache: the .so files travel with the tree).
+
+  tfhe_aes_amd/libfheaes.so         hipcc --offload-arch=gfx950   (HIP kernels + C ABI, the product)
+  tfhe_aes_amd/libfheaes_client.so  gcc -fopenmp                   (host Client: keygen / encrypt / decrypt)
+  oracle/liboracle.so               make -C oracle                 (CPU checker, test infrastructure)
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+
+ENGINE_SO = PKG / "libfheaes.so"
+CLIENT_SO = PKG / "libfheaes_client.so"
+ORACLE_SO = ROOT / "oracle" / "liboracle.so"
+
+ENGINE_SOURCES = [CSRC / "engine.hip"]
+ENGINE_HEADERS = sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.hpp")) + [ROOT / "include" / "fheaes.h"]
+
+
+def _stale(target: Path, deps) -> bool:
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(Path(d).exists() and Path(d).stat().st_mtime > t for d in deps)
+
+
+def _run(cmd, **kw):
+    res = subprocess.run(cmd, capture_output=True, text=True, **kw)
+    if res.returncode != 0:
+        raise RuntimeError("build failed: %s\n%s\n%s" % (" ".join(map(str, cmd)), res.stdout, res.stderr))
+    return res
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def engine_flags():
+    # -ffp-contract=off: the canonical arithmetic only fuses where the source says fma()
+    return [
+        "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        "-ffp-contract=off", "-fno-fast-math", "-Wall",
+        "-Wno-unused-function", "-I", str(ROOT / "include"), "-I", str(CSRC),
+    ]
+
+
+def build_engine(force: bool = False, extra=()) -> Path:
+    if force or _stale(ENGINE_SO, ENGINE_SOURCES + ENGINE_HEADERS):
+        cmd = [hipcc_path()] + engine_flags() + list(extra) + ["-o", str(ENGINE_SO)] + [str(s) for s in ENGINE_SOURCES]
+        _run(cmd)
+    return ENGINE_SO
+
+
+def build_client(force: bool = False) -> Path:
+    src = CSRC / "client.c"
+    if force or _stale(CLIENT_SO, [src, ROOT / "include" / "fheaes.h"]):
+        _run(["gcc", "-O3", "-mavx2", "-mfma", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-fPIC",
+              "-shared", "-std=gnu11", "-Wall", "-o", str(CLIENT_SO), str(src), "-lm"])
+    return CLIENT_SO
+
+
+def build_oracle(force: bool = False) -> Path:
+    src = ROOT / "oracle" / "fheaes_oracle.c"
+    if force or _stale(ORACLE_SO, [src]):
+        _run(["make", "-C", str(ROOT / "oracle"), "-B", "liboracle.so"])
+    return ORACLE_SO
+
+
+def build_all(force: bool = False):
+    return build_engine(force), build_client(force), build_oracle(force)

@@ -1,0 +1,189 @@
+"""Host-side ``Client``: key generation, per-bit encryption, decryption and verification.
+
+Mirrors /root/reference/src/client/client.rs:59-218 (``Client::new``, ``client_encrypt``,
+``client_decrypt_and_verify``, ``test_verify``) over flat ``uint64`` arrays instead of
+tfhe-rs containers.  The heavy loops live in csrc/client.c (libfheaes_client.so).
+
+Array conventions (see include/fheaes.h):
+  byte  = [8][kN+1]   (block j = bit j, LSB first)
+  state = [16][8][kN+1], byte index = 4*col + row, byte 0 = MSB of the u128 (client.rs:126-129)
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _build
+from .params import PARAM_OPT, CParams, WopbsParameters
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        path = _build.build_client()
+        lib = ctypes.CDLL(str(path))
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        u64p = ctypes.POINTER(ctypes.c_uint64)
+        pp = ctypes.POINTER(CParams)
+        lib.fheaes_client_gen_secret_keys.argtypes = [pp, ctypes.c_uint64, u8p, u8p]
+        lib.fheaes_client_gen_ksk.argtypes = [pp, ctypes.c_uint64, u8p, u8p, ctypes.c_double, u64p]
+        lib.fheaes_client_gen_bsk.argtypes = [pp, ctypes.c_uint64, u8p, u8p, ctypes.c_double, u64p]
+        lib.fheaes_client_gen_pfpksk.argtypes = [pp, ctypes.c_uint64, u8p, ctypes.c_double, u64p]
+        lib.fheaes_client_encrypt_bits.argtypes = [pp, ctypes.c_uint64, u8p, ctypes.c_double, u8p, ctypes.c_uint64, u64p]
+        lib.fheaes_client_decrypt_bits.argtypes = [pp, u8p, u64p, ctypes.c_uint64, u8p, u64p]
+        lib.fheaes_client_phase_small.argtypes = [pp, u8p, u64p, ctypes.c_uint64, u64p]
+        lib.fheaes_client_glwe_phase.argtypes = [pp, u8p, u64p, ctypes.c_uint64, u64p]
+        for f in (lib.fheaes_client_gen_secret_keys, lib.fheaes_client_gen_ksk, lib.fheaes_client_gen_bsk,
+                  lib.fheaes_client_gen_pfpksk, lib.fheaes_client_encrypt_bits, lib.fheaes_client_decrypt_bits,
+                  lib.fheaes_client_phase_small, lib.fheaes_client_glwe_phase):
+            f.restype = None
+        _lib = lib
+    return _lib
+
+
+def _u8(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+def _u64(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+
+
+@dataclass
+class ServerKeys:
+    """What ``client_encrypt`` hands to ``Server::new`` (client.rs:143): the evaluation keys."""
+
+    params: WopbsParameters
+    ksk: np.ndarray      # [kN][ks_level][n+1]
+    bsk: np.ndarray      # [n][pbs_level][k+1][k+1][N]   standard domain
+    pfpksk: np.ndarray   # [k+1][kN+1][pfks_level][(k+1)N]
+
+
+def u128_to_bytes(x: int) -> list[int]:
+    """state byte i = bits [8*(15-i), 8*(16-i)) of the u128 (client.rs:126-129)."""
+    return [(x >> (8 * (15 - i))) & 0xFF for i in range(16)]
+
+
+def bytes_to_u128(b) -> int:
+    v = 0
+    for i, x in enumerate(b):
+        v |= int(x) << (8 * (15 - i))
+    return v
+
+
+class Client:
+    """``Client::new`` (client.rs:70): generates the secret and evaluation keys from ``seed``."""
+
+    def __init__(self, number_of_outputs: int = 1, iv: int = 0, key: int = 0,
+                 params: WopbsParameters = PARAM_OPT, seed: int = 0xAE50001):
+        self.params = params
+        self.number_of_outputs = number_of_outputs
+        self.iv = iv
+        self.key = key
+        self.seed = seed
+        self._enc_counter = 0
+        lib = _load()
+        self._c = params.c_struct()
+        self.lwe_sk = np.zeros(params.n, dtype=np.uint8)
+        self.glwe_sk = np.zeros(params.big, dtype=np.uint8)
+        lib.fheaes_client_gen_secret_keys(ctypes.byref(self._c), seed, _u8(self.lwe_sk), _u8(self.glwe_sk))
+        self._server_keys = None
+
+    # -- keys -----------------------------------------------------------------
+    def server_keys(self) -> ServerKeys:
+        """gen_keys_radix + WopbsKey::new_wopbs_key_only_for_wopbs (client.rs:106-107)."""
+        if self._server_keys is None:
+            p, lib = self.params, _load()
+            ksk = np.empty(p.ksk_words, dtype=np.uint64)
+            bsk = np.empty(p.bsk_words, dtype=np.uint64)
+            pf = np.empty(p.pfpksk_words, dtype=np.uint64)
+            lib.fheaes_client_gen_ksk(ctypes.byref(self._c), self.seed, _u8(self.lwe_sk), _u8(self.glwe_sk),
+                                      p.lwe_noise_std, _u64(ksk))
+            lib.fheaes_client_gen_bsk(ctypes.byref(self._c), self.seed, _u8(self.lwe_sk), _u8(self.glwe_sk),
+                                      p.glwe_noise_std, _u64(bsk))
+            lib.fheaes_client_gen_pfpksk(ctypes.byref(self._c), self.seed, _u8(self.glwe_sk), p.pfks_noise_std, _u64(pf))
+            self._server_keys = ServerKeys(p, ksk, bsk, pf)
+        return self._server_keys
+
+    # -- encryption -----------------------------------------------------------
+    def encrypt_bits(self, bits: np.ndarray) -> np.ndarray:
+        """LWE encryptions (big key, glwe noise: EncryptionKeyChoice::Big) of an array of bits; adds a last axis kN+1."""
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        out = np.empty(bits.shape + (self.params.big1,), dtype=np.uint64)
+        self._enc_counter += 1
+        _load().fheaes_client_encrypt_bits(ctypes.byref(self._c), self.seed + 0x1000 * self._enc_counter, _u8(self.glwe_sk),
+                                           self.params.glwe_noise_std, _u8(bits), bits.size, _u64(out))
+        return out
+
+    def encrypt_bytes(self, values) -> np.ndarray:
+        """cks.encrypt_without_padding per byte (client.rs:128): [len][8][kN+1]."""
+        v = np.asarray(values, dtype=np.uint64).reshape(-1)
+        bits = ((v[:, None] >> np.arange(8, dtype=np.uint64)[None, :]) & 1).astype(np.uint8)
+        return self.encrypt_bits(bits)
+
+    def encrypt_u128(self, x: int) -> np.ndarray:
+        """one AES state / key: [16][8][kN+1]"""
+        return self.encrypt_bytes(u128_to_bytes(x))
+
+    def client_encrypt(self):
+        """client.rs:123: (server keys, encrypted iv, encrypted key)."""
+        return self.server_keys(), self.encrypt_u128(self.iv), self.encrypt_u128(self.key)
+
+    # -- decryption -----------------------------------------------------------
+    def decrypt_bits(self, lwe: np.ndarray, return_phase: bool = False):
+        lwe = np.ascontiguousarray(lwe, dtype=np.uint64)
+        assert lwe.shape[-1] == self.params.big1
+        shape = lwe.shape[:-1]
+        bits = np.empty(shape, dtype=np.uint8)
+        phase = np.empty(shape, dtype=np.uint64)
+        count = int(np.prod(shape)) if shape else 1
+        _load().fheaes_client_decrypt_bits(ctypes.byref(self._c), _u8(self.glwe_sk), _u64(lwe), count, _u8(bits), _u64(phase))
+        return (bits, phase) if return_phase else bits
+
+    def decrypt_bytes(self, lwe: np.ndarray) -> np.ndarray:
+        """[..., 8, kN+1] -> [...] byte values (decrypt_without_padding, client.rs:154)."""
+        bits = self.decrypt_bits(lwe).astype(np.uint64)
+        return (bits << np.arange(8, dtype=np.uint64)).sum(axis=-1).astype(np.uint8)
+
+    def decrypt_u128(self, state: np.ndarray) -> int:
+        return bytes_to_u128(self.decrypt_bytes(state).reshape(16))
+
+    def phase_small(self, lwe_small: np.ndarray) -> np.ndarray:
+        lwe_small = np.ascontiguousarray(lwe_small, dtype=np.uint64)
+        shape = lwe_small.shape[:-1]
+        out = np.empty(shape, dtype=np.uint64)
+        _load().fheaes_client_phase_small(ctypes.byref(self._c), _u8(self.lwe_sk), _u64(lwe_small), out.size, _u64(out))
+        return out
+
+    def glwe_phase(self, glwe: np.ndarray) -> np.ndarray:
+        """[..., (k+1)N] -> [..., N] phases B - sum A_m S_m"""
+        glwe = np.ascontiguousarray(glwe, dtype=np.uint64)
+        shape = glwe.shape[:-1]
+        out = np.empty(shape + (self.params.N,), dtype=np.uint64)
+        count = int(np.prod(shape)) if shape else 1
+        _load().fheaes_client_glwe_phase(ctypes.byref(self._c), _u8(self.glwe_sk), _u64(glwe), count, _u64(out))
+        return out
+
+    # -- verification (client.rs:147-216) --------------------------------------
+    def client_decrypt_and_verify(self, states) -> None:
+        """decrypt every CTR output block and compare with AES-128(key, iv + index)."""
+        from .aes_clear import aes128_encrypt_block
+
+        assert len(states) == self.number_of_outputs
+        for index, st in enumerate(states):
+            got = self.decrypt_u128(st)
+            want = aes128_encrypt_block(self.key, (self.iv + index) & ((1 << 128) - 1))
+            assert got == want, "block %d: FHE %032x != AES %032x" % (index, got, want)
+
+    def test_verify(self, state_enc, state_dec) -> None:
+        from .aes_clear import aes128_encrypt_block
+
+        got = self.decrypt_u128(state_enc)
+        want = aes128_encrypt_block(self.key, self.iv)
+        assert got == want, "enc: FHE %032x != AES %032x" % (got, want)
+        back = self.decrypt_u128(state_dec)
+        assert back == self.iv, "dec: FHE %032x != %032x" % (back, self.iv)

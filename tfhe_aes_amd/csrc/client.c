@@ -1,0 +1,252 @@
+/*
+ * client.c -- host-side Client of the FHE-AES engine (libfheaes_client.so, plain C + OpenMP).
+ *
+ * Mirrors the reference's Client (src/client/client.rs:59-218): key generation
+ * (gen_keys_radix + WopbsKey::new_wopbs_key_only_for_wopbs, client.rs:106-107), per-bit
+ * encryption without padding (client.rs:128,137) and decryption (client.rs:154).  It exists
+ * so that synthetic inputs of the reference's shape can be produced without tfhe-rs; it is
+ * NOT on the hot path and contains no FFT: secrets are binary, so every key row is a
+ * shift-add negacyclic product.
+ *
+ * Key layouts (shared with include/fheaes.h; level index 0 = most significant level):
+ *   small key  s  [n]  bits;  GLWE key S [k][N] bits;  big LWE key = S flattened (kN bits)
+ *   KSK    [kN][ks_level][n+1]              row (i,l) = LWE_s ( S_flat[i] * 2^(64-b(l+1)) )
+ *   BSK    [n][pbs_level][k+1][k+1][N]      GGSW(s_i): row (l,r) = GLWE_S(0) + s_i*2^(64-b(l+1)) on poly r
+ *   PFPKSK [k+1][kN+1][pfks_level][(k+1)N]  row (r,i,l) = GLWE_S( f_r(sigma_i * 2^(64-b(l+1))) ),
+ *          sigma_i = S_flat[i] (i<kN), sigma_kN = -1;  f_r(x) = -x*S_r(X) (r<k), f_k(x) = x
+ * 
+ *
+ * Randomness: xoshiro256** seeded per key row from (seed, tag, row) through splitmix64, so the
+ * output does not depend on the thread count.  Gaussian noise by the Marsaglia polar method
+ * with a series logarithm (only + - * / sqrt: no libm dependence, bit-reproducible).
+ * Synthetic-data quality, not a CSPRNG.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "../../include/fheaes.h"
+
+#define NPOLY 512
+
+/* ---------------------------------------------------------------- PRNG */
+typedef struct { uint64_t s[4]; } rng_t;
+
+static inline uint64_t splitmix64(uint64_t *x)
+{
+    uint64_t z = (*x += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+static void rng_seed(rng_t *r, uint64_t seed, uint64_t tag, uint64_t row)
+{
+    uint64_t x = seed ^ (tag * 0xD6E8FEB86659FD93ULL) ^ (row * 0xA24BAED4963EE407ULL);
+    for (int i = 0; i < 4; ++i) r->s[i] = splitmix64(&x);
+}
+
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+static inline uint64_t rng_next(rng_t *r)
+{
+    uint64_t *s = r->s;
+    uint64_t result = rotl64(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl64(s[3], 45);
+    return result;
+}
+
+/* ln(x) for x in (0,1], by exponent split + atanh series; deterministic IEEE ops only */
+static double det_log(double x)
+{
+    int e = 0;
+    while (x < 0.70710678118654752) { x *= 2.0; --e; }
+    while (x >= 1.4142135623730951) { x *= 0.5; ++e; }
+    double z = (x - 1.0) / (x + 1.0), z2 = z * z, term = z, sum = 0.0;
+    for (int kk = 1; kk <= 41; kk += 2) { sum += term / (double)kk; term *= z2; }
+    return 2.0 * sum + (double)e * 0.69314718055994531;
+}
+
+/* one N(0,1) sample */
+static double rng_gauss(rng_t *r)
+{
+    for (;;) {
+        double u = (double)(int64_t)(rng_next(r) >> 11) * 0x1p-52 - 1.0;
+        double v = (double)(int64_t)(rng_next(r) >> 11) * 0x1p-52 - 1.0;
+        double s = u * u + v * v;
+        if (s > 0.0 && s < 1.0) return u * sqrt(-2.0 * det_log(s) / s);
+    }
+}
+
+static inline uint64_t noise_word(rng_t *r, double sigma)
+{
+    if (sigma <= 0.0) return 0;
+    double e = rint(rng_gauss(r) * sigma * 0x1p64);
+    return (uint64_t)(int64_t)e;
+}
+
+/* ---------------------------------------------------------------- helpers */
+/* body += A (*) S for a binary S given as the list of its set positions */
+static void nega_mac_binary(const uint64_t *a, const int *pos, int npos, uint64_t *body)
+{
+    for (int q = 0; q < npos; ++q) {
+        int t = pos[q];
+        for (int j = 0; j < NPOLY - t; ++j) body[j + t] += a[j];
+        for (int j = NPOLY - t; j < NPOLY; ++j) body[j + t - NPOLY] -= a[j];
+    }
+}
+
+static int build_positions(const uint8_t *bits, int *pos)
+{
+    int c = 0;
+    for (int j = 0; j < NPOLY; ++j) if (bits[j]) pos[c++] = j;
+    return c;
+}
+
+/* fresh GLWE_S(0): mask uniform, body = sum A_m S_m + e */
+static void glwe_encrypt_zero(rng_t *r, int k, const int *pos, const int *npos, double sigma, uint64_t *ct)
+{
+    uint64_t *body = ct + (size_t)k * NPOLY;
+    for (int m = 0; m < k; ++m) for (int j = 0; j < NPOLY; ++j) ct[(size_t)m * NPOLY + j] = rng_next(r);
+    for (int j = 0; j < NPOLY; ++j) body[j] = noise_word(r, sigma);
+    for (int m = 0; m < k; ++m) nega_mac_binary(ct + (size_t)m * NPOLY, pos + (size_t)m * NPOLY, npos[m], body);
+}
+
+/* ---------------------------------------------------------------- API */
+void fheaes_client_gen_secret_keys(const fheaes_params *p, uint64_t seed, uint8_t *lwe_sk /*[n]*/, uint8_t *glwe_sk /*[k*N]*/)
+{
+    rng_t r;
+    rng_seed(&r, seed, 1, 0);
+    for (uint32_t i = 0; i < p->lwe_dimension; ++i) lwe_sk[i] = (uint8_t)(rng_next(&r) >> 63);
+    rng_seed(&r, seed, 2, 0);
+    for (uint32_t i = 0; i < p->glwe_dimension * NPOLY; ++i) glwe_sk[i] = (uint8_t)(rng_next(&r) >> 63);
+}
+
+void fheaes_client_gen_ksk(const fheaes_params *p, uint64_t seed, const uint8_t *lwe_sk, const uint8_t *glwe_sk,
+                           double sigma_lwe, uint64_t *ksk)
+{
+    int n = (int)p->lwe_dimension, big = (int)(p->glwe_dimension * NPOLY), L = (int)p->ks_level, b = (int)p->ks_base_log;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < big; ++i) {
+        rng_t r;
+        rng_seed(&r, seed, 3, (uint64_t)i);
+        for (int l = 0; l < L; ++l) {
+            uint64_t *row = ksk + ((size_t)i * L + l) * (n + 1);
+            uint64_t body = noise_word(&r, sigma_lwe);
+            for (int j = 0; j < n; ++j) { row[j] = rng_next(&r); if (lwe_sk[j]) body += row[j]; }
+            if (glwe_sk[i]) body += 1ULL << (64 - b * (l + 1));
+            row[n] = body;
+        }
+    }
+}
+
+void fheaes_client_gen_bsk(const fheaes_params *p, uint64_t seed, const uint8_t *lwe_sk, const uint8_t *glwe_sk,
+                           double sigma_glwe, uint64_t *bsk)
+{
+    int n = (int)p->lwe_dimension, k = (int)p->glwe_dimension, k1 = k + 1, L = (int)p->pbs_level, b = (int)p->pbs_base_log;
+    size_t gsz = (size_t)k1 * NPOLY;
+    int *pos = (int *)malloc((size_t)k * NPOLY * sizeof(int));
+    int npos[16];
+    for (int m = 0; m < k; ++m) npos[m] = build_positions(glwe_sk + (size_t)m * NPOLY, pos + (size_t)m * NPOLY);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        rng_t r;
+        rng_seed(&r, seed, 4, (uint64_t)i);
+        for (int l = 0; l < L; ++l) for (int rr = 0; rr < k1; ++rr) {
+            uint64_t *ct = bsk + (((size_t)i * L + l) * k1 + rr) * gsz;
+            glwe_encrypt_zero(&r, k, pos, npos, sigma_glwe, ct);
+            if (lwe_sk[i]) ct[(size_t)rr * NPOLY] += 1ULL << (64 - b * (l + 1));
+        }
+    }
+    free(pos);
+}
+
+void fheaes_client_gen_pfpksk(const fheaes_params *p, uint64_t seed, const uint8_t *glwe_sk, double sigma_pfks, uint64_t *pfpksk)
+{
+    int k = (int)p->glwe_dimension, k1 = k + 1, L = (int)p->pfks_level, b = (int)p->pfks_base_log;
+    int big = k * NPOLY, big1 = big + 1;
+    size_t gsz = (size_t)k1 * NPOLY;
+    int *pos = (int *)malloc((size_t)k * NPOLY * sizeof(int));
+    int npos[16];
+    for (int m = 0; m < k; ++m) npos[m] = build_positions(glwe_sk + (size_t)m * NPOLY, pos + (size_t)m * NPOLY);
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int rr = 0; rr < k1; ++rr) for (int i = 0; i < big1; ++i) {
+        rng_t r;
+        rng_seed(&r, seed, 5, (uint64_t)rr * (uint64_t)big1 + (uint64_t)i);
+        /* sigma_i in {0, 1, -1} */
+        int sig = (i < big) ? (int)glwe_sk[i] : -1;
+        for (int l = 0; l < L; ++l) {
+            uint64_t *ct = pfpksk + (((size_t)rr * big1 + i) * L + l) * gsz;
+            uint64_t *body = ct + (size_t)k * NPOLY;
+            glwe_encrypt_zero(&r, k, pos, npos, sigma_pfks, ct);
+            if (sig == 0) continue;
+            uint64_t g = 1ULL << (64 - b * (l + 1));
+            uint64_t x = (sig > 0) ? g : (uint64_t)0 - g;            /* sigma_i * g_l */
+            if (rr == k) body[0] += x;                               /* f_k(x) = x */
+            else for (int j = 0; j < NPOLY; ++j) if (glwe_sk[(size_t)rr * NPOLY + j]) body[j] -= x;  /* -x * S_r(X) */
+        }
+    }
+    free(pos);
+}
+
+/* encrypt_without_padding (client.rs:128): `count` bits -> LWE under the big key, bit at the MSB */
+void fheaes_client_encrypt_bits(const fheaes_params *p, uint64_t seed, const uint8_t *glwe_sk, double sigma,
+                                const uint8_t *bits, uint64_t count, uint64_t *lwe_out)
+{
+    int big = (int)(p->glwe_dimension * NPOLY);
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < (int64_t)count; ++q) {
+        rng_t r;
+        rng_seed(&r, seed, 6, (uint64_t)q);
+        uint64_t *ct = lwe_out + (size_t)q * (big + 1);
+        uint64_t body = noise_word(&r, sigma);
+        for (int j = 0; j < big; ++j) { ct[j] = rng_next(&r); if (glwe_sk[j]) body += ct[j]; }
+        body += (uint64_t)(bits[q] & 1) << 63;
+        ct[big] = body;
+    }
+}
+
+/* decrypt_without_padding (client.rs:154): bit = round(phase / 2^63); phase_out (optional) = raw phases */
+void fheaes_client_decrypt_bits(const fheaes_params *p, const uint8_t *glwe_sk, const uint64_t *lwe_in, uint64_t count,
+                                uint8_t *bits_out, uint64_t *phase_out)
+{
+    int big = (int)(p->glwe_dimension * NPOLY);
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < (int64_t)count; ++q) {
+        const uint64_t *ct = lwe_in + (size_t)q * (big + 1);
+        uint64_t ph = ct[big];
+        for (int j = 0; j < big; ++j) if (glwe_sk[j]) ph -= ct[j];
+        if (phase_out) phase_out[q] = ph;
+        bits_out[q] = (uint8_t)(((ph + (1ULL << 62)) >> 63) & 1);
+    }
+}
+
+/* phases of small-key LWEs / GLWE bodies, for noise diagnostics in tests */
+void fheaes_client_phase_small(const fheaes_params *p, const uint8_t *lwe_sk, const uint64_t *lwe_in, uint64_t count, uint64_t *phase_out)
+{
+    int n = (int)p->lwe_dimension;
+    for (uint64_t q = 0; q < count; ++q) {
+        const uint64_t *ct = lwe_in + (size_t)q * (n + 1);
+        uint64_t ph = ct[n];
+        for (int j = 0; j < n; ++j) if (lwe_sk[j]) ph -= ct[j];
+        phase_out[q] = ph;
+    }
+}
+
+void fheaes_client_glwe_phase(const fheaes_params *p, const uint8_t *glwe_sk, const uint64_t *glwe_in, uint64_t count, uint64_t *phase_out /*[count][N]*/)
+{
+    int k = (int)p->glwe_dimension;
+    size_t gsz = (size_t)(k + 1) * NPOLY;
+    int *pos = (int *)malloc((size_t)k * NPOLY * sizeof(int));
+    int npos[16];
+    for (int m = 0; m < k; ++m) npos[m] = build_positions(glwe_sk + (size_t)m * NPOLY, pos + (size_t)m * NPOLY);
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < (int64_t)count; ++q) {
+        const uint64_t *ct = glwe_in + (size_t)q * gsz;
+        uint64_t tmp[NPOLY];
+        memset(tmp, 0, sizeof tmp);
+        for (int m = 0; m < k; ++m) nega_mac_binary(ct + (size_t)m * NPOLY, pos + (size_t)m * NPOLY, npos[m], tmp);
+        for (int j = 0; j < NPOLY; ++j) phase_out[(size_t)q * NPOLY + j] = ct[(size_t)k * NPOLY + j] - tmp[j];
+    }
+    free(pos);
+}
