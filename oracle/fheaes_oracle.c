@@ -41,7 +41,8 @@
  *     conjugate multiply cmulc(x,w): re = fma(xr,wr,  xi*wi ); im = fma(xi,wr,-(xr*wi))
  *     multiplication by 1 / +-i is a copy / swap-negate;
  *   - pointwise multiply-accumulate is one sequential chain per (output poly, point),
- *     level-major then row:   re = fma(dr,br,re); re = fma(-di,bi,re);
+ *     levels from the LEAST significant (l = L-1) to the most significant (l = 0), rows r
+ *     ascending inside a level:  re = fma(dr,br,re); re = fma(-di,bi,re);
  *                             im = fma(dr,bi,im); im = fma( di,br,im);
  *   - back-conversion: w = v*2^-72; w -= rint(w); r = rint(w*2^64) -> int64, wrapping add;
  *   - twiddles: psi^j = exp(i*pi*j/512) from long-double half-angle recurrences (see
@@ -358,7 +359,8 @@ static void ext_product_add(int k1, int level, int base_log, const double *gf,
     double fr[HALF], fi[HALF];
     for (int c = 0; c < k1; ++c) {
         for (int t = 0; t < HALF; ++t) { fr[t] = 0.0; fi[t] = 0.0; }
-        for (int lr = 0; lr < rows; ++lr) {
+        for (int l = level - 1; l >= 0; --l) for (int r = 0; r < k1; ++r) {   /* least significant level first */
+            int lr = l * k1 + r;
             const double *dr = D + (size_t)lr * NPOLY, *di = dr + HALF;
             const double *br = gf + ((size_t)lr * k1 + c) * NPOLY, *bi = br + HALF;
             for (int t = 0; t < HALF; ++t) {

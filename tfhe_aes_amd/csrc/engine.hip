@@ -1,0 +1,965 @@
+// engine.hip -- C ABI (include/fheaes.h) and host-side schedule of the MI355X FHE-AES engine.
+//
+// The host code here is the native counterpart of the reference's Server
+// (src/server/server.rs:24-282) and S-Box front end (src/server/sbox/sbox.rs:46-97,
+// src/server/sbox/many_wopbs.rs:31-116): it owns the device copies of the keys, the workspace,
+// the precomputed AES LUT sets, and enqueues the kernels of kern_*.h on one HIP stream.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fheaes.h"
+#include "fft_dev.h"
+#include "kern_extprod.h"
+#include "kern_keyswitch.h"
+#include "kern_linear.h"
+
+#define FHEAES_VERSION_STR "fheaes-mi355x 0.1 (gfx950)"
+#define KS_TM 32
+#define MAX_CHUNK_BITS 32768ull
+
+namespace {
+
+std::string g_create_error;
+
+// ---------------------------------------------------------------------------------------------
+// host tables
+// ---------------------------------------------------------------------------------------------
+struct HostTwiddles {
+    double psi_re[FHE_N], psi_im[FHE_N];
+    HostTwiddles()
+    {
+        // psi^j = exp(i pi j/512): half-angle recurrences in long double, products of the
+        // binary powers, octant symmetry (same specification as oracle/fheaes_oracle.c).
+        long double bc[8], bs[8];
+        bc[7] = sqrtl(0.5L); bs[7] = bc[7];
+        for (int m = 6; m >= 0; --m) {
+            long double c = sqrtl((1.0L + bc[m + 1]) / 2.0L);
+            long double s = bs[m + 1] / (2.0L * c);
+            bc[m] = c; bs[m] = s;
+        }
+        for (int j = 0; j <= 128; ++j) {
+            long double pr = 1.0L, pi = 0.0L;
+            for (int m = 0; m < 8; ++m) if ((j >> m) & 1) {
+                long double nr = pr * bc[m] - pi * bs[m];
+                long double ni = pr * bs[m] + pi * bc[m];
+                pr = nr; pi = ni;
+            }
+            psi_re[j] = (double)pr; psi_im[j] = (double)pi;
+        }
+        psi_re[0] = 1.0; psi_im[0] = 0.0;
+        psi_im[128] = psi_re[128];
+        for (int j = 129; j <= 256; ++j) { psi_re[j] = psi_im[256 - j]; psi_im[j] = psi_re[256 - j]; }
+        for (int j = 257; j < 512; ++j) { psi_re[j] = -psi_re[512 - j]; psi_im[j] = psi_im[512 - j]; }
+    }
+    void w256(int m, double &re, double &im) const
+    {
+        int e = 4 * m;
+        if (e < 512) { re = psi_re[e]; im = psi_im[e]; }
+        else { re = -psi_re[e - 512]; im = -psi_im[e - 512]; }
+    }
+};
+
+const HostTwiddles &twiddles()
+{
+    static HostTwiddles t;
+    return t;
+}
+
+// AES tables from the field definition (tables/table.rs, sbox.rs:20-42)
+struct AesTables {
+    uint8_t sbox[256], inv[256];
+    static uint8_t mul(uint8_t a, uint8_t b)
+    {
+        uint8_t r = 0;
+        for (int i = 0; i < 8; ++i) { if (b & 1) r ^= a; uint8_t hi = a & 0x80; a = (uint8_t)(a << 1); if (hi) a ^= 0x1B; b >>= 1; }
+        return r;
+    }
+    AesTables()
+    {
+        for (int x = 0; x < 256; ++x) {
+            uint8_t y = 0;
+            if (x) for (int c = 1; c < 256; ++c) if (mul((uint8_t)x, (uint8_t)c) == 1) { y = (uint8_t)c; break; }
+            uint8_t s = y, v = y;
+            for (int i = 0; i < 4; ++i) { v = (uint8_t)((v << 1) | (v >> 7)); s ^= v; }
+            s ^= 0x63;
+            sbox[x] = s; inv[s] = (uint8_t)x;
+        }
+    }
+};
+
+const AesTables &aes_tables()
+{
+    static AesTables t;
+    return t;
+}
+
+enum { LUTSET_ENC_ROUND = 0, LUTSET_SBOX, LUTSET_INV_SBOX, LUTSET_DEC_MUL, LUTSET_IDENTITY, LUTSET_COUNT };
+
+void gen_lut_host(uint32_t nb, const uint64_t *f, uint64_t *out)
+{
+    for (uint32_t idx = 0; idx < FHE_N; ++idx) {
+        uint64_t v = f[idx & ((1u << nb) - 1)];
+        for (uint32_t b = 0; b < nb; ++b) out[(size_t)b * FHE_N + idx] = ((v >> b) & 1ull) << 63;
+    }
+}
+
+int build_lutset_host(int which, std::vector<uint64_t> &out)
+{
+    const AesTables &T = aes_tables();
+    uint64_t f[4][256];
+    int n = 1;
+    for (int x = 0; x < 256; ++x) {
+        uint8_t s = T.sbox[x];
+        switch (which) {
+        case LUTSET_ENC_ROUND: f[0][x] = s; f[1][x] = AesTables::mul(s, 2); f[2][x] = AesTables::mul(s, 3); n = 3; break;
+        case LUTSET_SBOX: f[0][x] = s; break;
+        case LUTSET_INV_SBOX: f[0][x] = T.inv[x]; break;
+        case LUTSET_DEC_MUL:
+            f[0][x] = AesTables::mul((uint8_t)x, 9); f[1][x] = AesTables::mul((uint8_t)x, 11);
+            f[2][x] = AesTables::mul((uint8_t)x, 13); f[3][x] = AesTables::mul((uint8_t)x, 14); n = 4; break;
+        default: f[0][x] = (uint64_t)x; break;
+        }
+    }
+    out.assign((size_t)n * 8 * FHE_N, 0);
+    for (int i = 0; i < n; ++i) gen_lut_host(8, f[i], out.data() + (size_t)i * 8 * FHE_N);
+    return n;
+}
+
+const int MC_ENC[4][4] = {{1, 2, 0, 0}, {0, 1, 2, 0}, {0, 0, 1, 2}, {2, 0, 0, 1}};
+const int MC_DEC[4][4] = {{3, 1, 2, 0}, {0, 3, 1, 2}, {2, 0, 3, 1}, {1, 2, 0, 3}};
+
+GatherTable table_enc_round()
+{
+    GatherTable t{}; t.terms = 4;
+    for (int col = 0; col < 4; ++col) for (int row = 0; row < 4; ++row) for (int r2 = 0; r2 < 4; ++r2) {
+        t.src[4 * col + row][r2] = (int8_t)(4 * ((col + r2) & 3) + r2);
+        t.lut[4 * col + row][r2] = (int8_t)MC_ENC[row][r2];
+    }
+    return t;
+}
+GatherTable table_shift_rows(bool inverse)
+{
+    GatherTable t{}; t.terms = 1;
+    for (int col = 0; col < 4; ++col) for (int row = 0; row < 4; ++row) {
+        t.src[4 * col + row][0] = (int8_t)(4 * ((inverse ? col - row : col + row) & 3) + row);
+        t.lut[4 * col + row][0] = 0;
+    }
+    return t;
+}
+GatherTable table_dec_mix()
+{
+    GatherTable t{}; t.terms = 4;
+    for (int col = 0; col < 4; ++col) for (int row = 0; row < 4; ++row) for (int r2 = 0; r2 < 4; ++r2) {
+        t.src[4 * col + row][r2] = (int8_t)(4 * col + r2);
+        t.lut[4 * col + row][r2] = (int8_t)MC_DEC[row][r2];
+    }
+    return t;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct fheaes_ctx {
+    fheaes_params p{};
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+    // shapes
+    uint32_t n = 0, k = 0, k1 = 0, big = 0, big1 = 0;
+    // keys
+    uint64_t *ksk = nullptr, *ksk_init = nullptr, *pfpksk = nullptr, *pfpksk_init = nullptr;
+    double2 *bskf = nullptr;
+    bool have_keys = false;
+    // tables
+    double2 *psi_d = nullptr, *tw_d = nullptr;
+    FftConsts fc{};
+    uint64_t *lutset_d[LUTSET_COUNT] = {};
+    int lutset_n[LUTSET_COUNT] = {};
+    // workspace
+    DevBuf ws_small, ws_pbs, ws_ggsw, ws_ggswf, ws_vp, ws_tmp_a, ws_tmp_b, ws_luts, ws_misc;
+    // profiling
+    bool prof = false;
+    struct Pending { hipEvent_t a, b; int stage; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> free_events;
+    double stage_ms[FHEAES_STAGE_COUNT] = {};
+    uint64_t stage_launches[FHEAES_STAGE_COUNT] = {};
+    uint64_t stage_units[FHEAES_STAGE_COUNT] = {};
+
+    int fail(int code, const char *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) return (ctx)->fail(FHEAES_ERR_DEVICE, "%s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+#define TRY(expr)                  \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != FHEAES_OK) return rc__; \
+    } while (0)
+
+namespace {
+
+int ensure(fheaes_ctx *c, DevBuf &b, size_t bytes)
+{
+    if (b.bytes >= bytes) return FHEAES_OK;
+    if (b.p) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) { b.p = nullptr; return c->fail(FHEAES_ERR_NOMEM, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e)); }
+    b.bytes = bytes;
+    return FHEAES_OK;
+}
+
+// ---- profiling -------------------------------------------------------------------------------
+int prof_flush(fheaes_ctx *c)
+{
+    for (auto &pe : c->pending) {
+        HIP_TRY(c, hipEventSynchronize(pe.b));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, pe.a, pe.b));
+        c->stage_ms[pe.stage] += ms;
+        c->free_events.push_back(pe.a);
+        c->free_events.push_back(pe.b);
+    }
+    c->pending.clear();
+    return FHEAES_OK;
+}
+
+struct StageScope {
+    fheaes_ctx *c;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    bool on;
+    StageScope(fheaes_ctx *ctx, int st, uint64_t units) : c(ctx), stage(st), on(ctx->prof)
+    {
+        c->stage_launches[stage] += 1;
+        c->stage_units[stage] += units;
+        if (!on) return;
+        if (c->pending.size() > 4096) prof_flush(c);
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!c->free_events.empty()) { e = c->free_events.back(); c->free_events.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+            return e;
+        };
+        a = get(); b = get();
+        if (a) (void)hipEventRecord(a, c->stream);
+    }
+    ~StageScope()
+    {
+        if (!on || !a || !b) return;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({a, b, stage});
+    }
+};
+
+// ---- kernel launchers ------------------------------------------------------------------------
+int launch_keyswitch(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *out)
+{
+    if (m == 0) return FHEAES_OK;
+    StageScope sc(c, FHEAES_STAGE_KEYSWITCH, m);
+    KeyswitchArgs a{};
+    a.in = in; a.in_stride = c->big1; a.n_in = c->big; a.body_index = (int32_t)c->big; a.body_col = c->n;
+    a.key = c->ksk; a.key_z_stride = 0; a.init = c->ksk_init; a.ncols = c->n + 1;
+    a.out = out; a.out_stride = c->n + 1; a.out_z_stride = 0; a.m = m;
+    dim3 grid((a.ncols + KS_THREADS - 1) / KS_THREADS, (unsigned)((m + KS_TM - 1) / KS_TM), 1);
+    hipLaunchKernelGGL((keyswitch_kernel<2, 6, KS_TM>), grid, dim3(KS_THREADS), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return FHEAES_OK;
+}
+
+// out: rows of one GGSW level: [m][out_stride] with key r at offset r*(k+1)N
+int launch_pfpks(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *out, uint64_t out_stride)
+{
+    if (m == 0) return FHEAES_OK;
+    StageScope sc(c, FHEAES_STAGE_PFPKS, m);
+    KeyswitchArgs a{};
+    const uint32_t gsz = c->k1 * FHE_N;
+    a.in = in; a.in_stride = c->big1; a.n_in = c->big1; a.body_index = -1; a.body_col = 0;
+    a.key = c->pfpksk; a.key_z_stride = (uint64_t)c->big1 * c->p.pfks_level * gsz; a.init = c->pfpksk_init; a.ncols = gsz;
+    a.out = out; a.out_stride = out_stride; a.out_z_stride = gsz; a.m = m;
+    dim3 grid((gsz + KS_THREADS - 1) / KS_THREADS, (unsigned)((m + KS_TM - 1) / KS_TM), c->k1);
+    hipLaunchKernelGGL((keyswitch_kernel<12, 3, KS_TM>), grid, dim3(KS_THREADS), 0, c->stream, a);
+    HIP_TRY(c, hipGetLastError());
+    return FHEAES_OK;
+}
+
+int launch_forward_fourier(fheaes_ctx *c, const uint64_t *in, uint64_t polys, double2 *out, int stage)
+{
+    if (polys == 0) return FHEAES_OK;
+    StageScope sc(c, stage, polys);
+    uint64_t wgs = (polys + EP_GROUPS - 1) / EP_GROUPS;
+    if (wgs > 8192) wgs = 8192;
+    hipLaunchKernelGGL(forward_fourier_kernel, dim3((unsigned)wgs), dim3(EP_THREADS), 0, c->stream, in, out, polys, c->psi_d, c->tw_d, c->fc);
+    HIP_TRY(c, hipGetLastError());
+    return FHEAES_OK;
+}
+
+int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_t level, uint64_t *out)
+{
+    if (m == 0) return FHEAES_OK;
+    StageScope sc(c, FHEAES_STAGE_BLIND_ROTATE, m);
+    ExtProdArgs a{};
+    a.ggsw = c->bskf; a.psi = c->psi_d; a.tw = c->tw_d; a.fc = c->fc;
+    a.out = out; a.count = m; a.iters = c->n; a.lwe_in = lwe_small;
+    const uint64_t half_delta = 1ull << (64 - c->p.cbs_base_log * level - 1);
+    a.tv_const = (uint64_t)0 - half_delta; a.body_shift = 1ull << 62; a.post_add = half_delta;
+    if (c->k1 == 5) {
+        constexpr int R = 3;
+        hipLaunchKernelGGL((extprod_rotate_kernel<5, 5, 8, R, false>), dim3((unsigned)((m + R - 1) / R)), dim3(EP_THREADS), 0, c->stream, a);
+    } else {
+        constexpr int R = 8;
+        hipLaunchKernelGGL((extprod_rotate_kernel<2, 5, 8, R, false>), dim3((unsigned)((m + R - 1) / R)), dim3(EP_THREADS), 0, c->stream, a);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return FHEAES_OK;
+}
+
+int launch_vertical_packing(fheaes_ctx *c, const double2 *ggswf, uint64_t n_inputs, uint32_t bits, const uint64_t *luts,
+                            uint32_t n_luts, int per_input, uint64_t *out)
+{
+    if (n_inputs == 0) return FHEAES_OK;
+    StageScope sc(c, FHEAES_STAGE_VERTICAL_PACKING, n_inputs * n_luts * bits);
+    ExtProdArgs a{};
+    a.ggsw = ggswf; a.psi = c->psi_d; a.tw = c->tw_d; a.fc = c->fc;
+    a.out = out; a.count = n_inputs * n_luts * bits; a.iters = bits;
+    a.luts = luts; a.n_luts = n_luts; a.lut_per_input = per_input ? 1 : 0; a.inst_per_input = n_luts * bits;
+    if (c->k1 == 5) {
+        constexpr int R = 3;
+        a.wg_per_input = (a.inst_per_input + R - 1) / R;
+        hipLaunchKernelGGL((extprod_rotate_kernel<5, 1, 15, R, true>), dim3((unsigned)(n_inputs * a.wg_per_input)), dim3(EP_THREADS), 0, c->stream, a);
+    } else {
+        constexpr int R = 8;
+        a.wg_per_input = (a.inst_per_input + R - 1) / R;
+        hipLaunchKernelGGL((extprod_rotate_kernel<2, 1, 15, R, true>), dim3((unsigned)(n_inputs * a.wg_per_input)), dim3(EP_THREADS), 0, c->stream, a);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return FHEAES_OK;
+}
+
+int launch_gather(fheaes_ctx *c, const uint64_t *src, uint32_t n_luts, const uint64_t *rk, uint64_t *out, uint64_t n_blocks, const GatherTable &t)
+{
+    if (n_blocks == 0) return FHEAES_OK;
+    StageScope sc(c, FHEAES_STAGE_LINEAR, n_blocks);
+    const uint32_t bw = 8 * c->big1;
+    dim3 grid((bw + 1023) / 1024, 16, (unsigned)n_blocks);
+    hipLaunchKernelGGL(gather_add_kernel, grid, dim3(256), 0, c->stream, src, n_luts, rk, out, n_blocks, bw, t);
+    HIP_TRY(c, hipGetLastError());
+    return FHEAES_OK;
+}
+
+int launch_add_bcast(fheaes_ctx *c, uint64_t *dst, const uint64_t *src, uint64_t words_per_block, uint64_t n_blocks)
+{
+    if (n_blocks == 0) return FHEAES_OK;
+    StageScope sc(c, FHEAES_STAGE_LINEAR, n_blocks);
+    uint64_t total = words_per_block * n_blocks;
+    unsigned grid = (unsigned)std::min<uint64_t>((total + 255) / 256, 16384);
+    hipLaunchKernelGGL(add_bcast_kernel, dim3(grid), dim3(256), 0, c->stream, dst, src, words_per_block, n_blocks);
+    HIP_TRY(c, hipGetLastError());
+    return FHEAES_OK;
+}
+
+int launch_add2(fheaes_ctx *c, uint64_t *dst, const uint64_t *a, const uint64_t *b, uint64_t words)
+{
+    StageScope sc(c, FHEAES_STAGE_LINEAR, 1);
+    unsigned grid = (unsigned)std::min<uint64_t>((words + 255) / 256, 16384);
+    hipLaunchKernelGGL(add2_kernel, dim3(grid), dim3(256), 0, c->stream, dst, a, b, words);
+    HIP_TRY(c, hipGetLastError());
+    return FHEAES_OK;
+}
+
+int check_keys(fheaes_ctx *c)
+{
+    if (!c) return FHEAES_ERR_INVALID;
+    if (!c->have_keys) return c->fail(FHEAES_ERR_NOKEYS, "evaluation keys have not been uploaded");
+    return FHEAES_OK;
+}
+
+// ---- many_wopbs_without_padding on device buffers ----------------------------------------------
+int wopbs_dev(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t n_inputs, uint32_t bits, const uint64_t *luts, uint32_t n_luts,
+              int per_input, uint64_t *lwe_out)
+{
+    if (bits < 1 || bits > 9) return c->fail(FHEAES_ERR_INVALID, "bits_per_input must be in 1..9 (got %u)", bits);
+    if (n_luts < 1) return c->fail(FHEAES_ERR_INVALID, "n_luts must be >= 1");
+    if (n_inputs == 0) return FHEAES_OK;
+    const uint64_t chunk_inputs = std::max<uint64_t>(1, MAX_CHUNK_BITS / bits);
+    const uint64_t ggsw_words = (uint64_t)c->k1 * c->k1 * FHE_N;    // cbs_level == 1
+    const uint64_t cap_bits = std::min<uint64_t>(n_inputs, chunk_inputs) * bits;
+    TRY(ensure(c, c->ws_small, cap_bits * (c->n + 1) * 8));
+    TRY(ensure(c, c->ws_pbs, cap_bits * c->big1 * 8));
+    TRY(ensure(c, c->ws_ggsw, cap_bits * ggsw_words * 8));
+    TRY(ensure(c, c->ws_ggswf, cap_bits * ggsw_words * 8));
+    for (uint64_t i0 = 0; i0 < n_inputs; i0 += chunk_inputs) {
+        const uint64_t ni = std::min<uint64_t>(chunk_inputs, n_inputs - i0);
+        const uint64_t m = ni * bits;
+        const uint64_t *in = lwe_in + i0 * bits * c->big1;
+        TRY(launch_keyswitch(c, in, m, (uint64_t *)c->ws_small.p));
+        TRY(launch_cbs_pbs(c, (const uint64_t *)c->ws_small.p, m, 1, (uint64_t *)c->ws_pbs.p));
+        TRY(launch_pfpks(c, (const uint64_t *)c->ws_pbs.p, m, (uint64_t *)c->ws_ggsw.p, ggsw_words));
+        TRY(launch_forward_fourier(c, (const uint64_t *)c->ws_ggsw.p, m * c->k1 * c->k1, (double2 *)c->ws_ggswf.p, FHEAES_STAGE_GGSW_FFT));
+        const uint64_t *l = per_input ? luts + i0 * n_luts * bits * FHE_N : luts;
+        TRY(launch_vertical_packing(c, (const double2 *)c->ws_ggswf.p, ni, bits, l, n_luts, per_input, lwe_out + i0 * n_luts * bits * c->big1));
+    }
+    return FHEAES_OK;
+}
+
+// stage host arrays through device temporaries
+struct Staged {
+    fheaes_ctx *c;
+    std::vector<void *> bufs;
+    explicit Staged(fheaes_ctx *ctx) : c(ctx) {}
+    ~Staged()
+    {
+        (void)hipStreamSynchronize(c->stream);
+        for (void *b : bufs) (void)hipFree(b);
+    }
+    int alloc(void **out, size_t bytes)
+    {
+        hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+        if (e != hipSuccess) return c->fail(FHEAES_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        bufs.push_back(*out);
+        return FHEAES_OK;
+    }
+    int in(const void *host, size_t bytes, void **dev)
+    {
+        TRY(alloc(dev, bytes));
+        HIP_TRY(c, hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+        return FHEAES_OK;
+    }
+    int out(void *host, const void *dev, size_t bytes)
+    {
+        HIP_TRY(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return FHEAES_OK;
+    }
+};
+
+int supported(const fheaes_params *p, std::string &why)
+{
+    char buf[256];
+    if (p->polynomial_size != FHE_N) { why = "polynomial_size must be 512"; return 0; }
+    if (p->glwe_dimension != 4 && p->glwe_dimension != 1) { why = "glwe_dimension must be 4 (PARAM_OPT) or 1 (toy)"; return 0; }
+    if (p->pbs_base_log != 8 || p->pbs_level != 5 || p->ks_base_log != 2 || p->ks_level != 6 || p->pfks_base_log != 12 ||
+        p->pfks_level != 3 || p->cbs_base_log != 15 || p->cbs_level != 1) {
+        snprintf(buf, sizeof buf, "unsupported gadget: kernels are instantiated for pbs(8,5) ks(2,6) pfks(12,3) cbs(15,1)");
+        why = buf;
+        return 0;
+    }
+    if (p->lwe_dimension < 1 || p->lwe_dimension > 4096) { why = "lwe_dimension out of range"; return 0; }
+    return 1;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *fheaes_version(void) { return FHEAES_VERSION_STR; }
+
+const char *fheaes_last_error(const fheaes_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int fheaes_get_twiddles(double *psi_out)
+{
+    if (!psi_out) return FHEAES_ERR_INVALID;
+    const HostTwiddles &t = twiddles();
+    for (int j = 0; j < FHE_N; ++j) { psi_out[2 * j] = t.psi_re[j]; psi_out[2 * j + 1] = t.psi_im[j]; }
+    return FHEAES_OK;
+}
+
+int fheaes_gen_lut(uint32_t nb_block, const uint64_t *f_table, uint64_t *lut_out)
+{
+    if (nb_block < 1 || nb_block > 9 || !f_table || !lut_out) return FHEAES_ERR_INVALID;
+    gen_lut_host(nb_block, f_table, lut_out);
+    return FHEAES_OK;
+}
+
+int fheaes_create(const fheaes_params *params, int device, fheaes_ctx **out)
+{
+    if (!params || !out) { g_create_error = "null argument"; return FHEAES_ERR_INVALID; }
+    std::string why;
+    if (!supported(params, why)) { g_create_error = why; return FHEAES_ERR_INVALID; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) { g_create_error = std::string("no HIP device: ") + hipGetErrorString(e); return FHEAES_ERR_DEVICE; }
+    if (device < 0 || device >= ndev) { g_create_error = "device ordinal out of range"; return FHEAES_ERR_INVALID; }
+    fheaes_ctx *c = new fheaes_ctx();
+    c->p = *params; c->device = device;
+    c->n = params->lwe_dimension; c->k = params->glwe_dimension; c->k1 = c->k + 1; c->big = c->k * FHE_N; c->big1 = c->big + 1;
+    auto bail = [&](const char *what, hipError_t err) {
+        g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+        fheaes_destroy(c);
+        return FHEAES_ERR_DEVICE;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    c->stream = c->own_stream;
+    // twiddle tables
+    const HostTwiddles &t = twiddles();
+    std::vector<double2> psi(FHE_H), tw(FHE_H);
+    for (int j = 0; j < FHE_H; ++j) { psi[j].x = t.psi_re[j]; psi[j].y = t.psi_im[j]; }
+    for (int k1 = 0; k1 < 16; ++k1) for (int b = 0; b < 16; ++b) { double re, im; t.w256((k1 * b) & 255, re, im); tw[16 * k1 + b].x = re; tw[16 * k1 + b].y = im; }
+    c->fc.c1 = t.psi_re[64]; c->fc.s1 = t.psi_im[64]; c->fc.h = t.psi_re[128];
+    if ((e = hipMalloc((void **)&c->psi_d, FHE_H * sizeof(double2))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void **)&c->tw_d, FHE_H * sizeof(double2))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemcpy(c->psi_d, psi.data(), FHE_H * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+    if ((e = hipMemcpy(c->tw_d, tw.data(), FHE_H * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+    // AES LUT sets, built once (the reference rebuilds them on every call: sbox.rs:54-60, :85-94)
+    for (int s = 0; s < LUTSET_COUNT; ++s) {
+        std::vector<uint64_t> h;
+        c->lutset_n[s] = build_lutset_host(s, h);
+        if ((e = hipMalloc((void **)&c->lutset_d[s], h.size() * 8)) != hipSuccess) return bail("hipMalloc", e);
+        if ((e = hipMemcpy(c->lutset_d[s], h.data(), h.size() * 8, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+    }
+    *out = c;
+    return FHEAES_OK;
+}
+
+void fheaes_destroy(fheaes_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &pe : c->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    for (auto ev : c->free_events) (void)hipEventDestroy(ev);
+    void *ptrs[] = {c->ksk, c->ksk_init, c->pfpksk, c->pfpksk_init, c->bskf, c->psi_d, c->tw_d,
+                    c->ws_small.p, c->ws_pbs.p, c->ws_ggsw.p, c->ws_ggswf.p, c->ws_vp.p, c->ws_tmp_a.p, c->ws_tmp_b.p, c->ws_luts.p, c->ws_misc.p};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (int s = 0; s < LUTSET_COUNT; ++s) if (c->lutset_d[s]) (void)hipFree(c->lutset_d[s]);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+size_t fheaes_key_words(const fheaes_ctx *c, int which)
+{
+    if (!c) return 0;
+    switch (which) {
+    case FHEAES_KEY_KSK: return (size_t)c->big * c->p.ks_level * (c->n + 1);
+    case FHEAES_KEY_BSK: return (size_t)c->n * c->p.pbs_level * c->k1 * c->k1 * FHE_N;
+    case FHEAES_KEY_PFPKSK: return (size_t)c->k1 * c->big1 * c->p.pfks_level * c->k1 * FHE_N;
+    default: return 0;
+    }
+}
+
+int fheaes_set_stream(fheaes_ctx *c, void *hip_stream)
+{
+    if (!c) return FHEAES_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return FHEAES_OK;
+}
+
+int fheaes_synchronize(fheaes_ctx *c)
+{
+    if (!c) return FHEAES_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FHEAES_OK;
+}
+
+int fheaes_reserve(fheaes_ctx *c, uint64_t max_bits)
+{
+    if (!c) return FHEAES_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint64_t bits = std::min<uint64_t>(max_bits, MAX_CHUNK_BITS);
+    const uint64_t ggsw_words = (uint64_t)c->k1 * c->k1 * FHE_N;
+    TRY(ensure(c, c->ws_small, bits * (c->n + 1) * 8));
+    TRY(ensure(c, c->ws_pbs, bits * c->big1 * 8));
+    TRY(ensure(c, c->ws_ggsw, bits * ggsw_words * 8));
+    TRY(ensure(c, c->ws_ggswf, bits * ggsw_words * 8));
+    return FHEAES_OK;
+}
+
+int fheaes_upload_keys(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, const uint64_t *pfpksk, int memspace)
+{
+    if (!c || !ksk || !bsk || !pfpksk) return c ? c->fail(FHEAES_ERR_INVALID, "null key pointer") : FHEAES_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t kw = fheaes_key_words(c, FHEAES_KEY_KSK), bw = fheaes_key_words(c, FHEAES_KEY_BSK), pw = fheaes_key_words(c, FHEAES_KEY_PFPKSK);
+    const hipMemcpyKind kind = memspace == FHEAES_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    c->have_keys = false;
+    if (!c->ksk) HIP_TRY(c, hipMalloc((void **)&c->ksk, kw * 8));
+    if (!c->pfpksk) HIP_TRY(c, hipMalloc((void **)&c->pfpksk, pw * 8));
+    if (!c->bskf) HIP_TRY(c, hipMalloc((void **)&c->bskf, bw * 8));
+    if (!c->ksk_init) HIP_TRY(c, hipMalloc((void **)&c->ksk_init, (size_t)(c->n + 1) * 8));
+    if (!c->pfpksk_init) HIP_TRY(c, hipMalloc((void **)&c->pfpksk_init, (size_t)c->k1 * c->k1 * FHE_N * 8));
+    HIP_TRY(c, hipMemcpyAsync(c->ksk, ksk, kw * 8, kind, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->pfpksk, pfpksk, pw * 8, kind, c->stream));
+    // BSK: standard domain -> Fourier (the reference holds it in Fourier form already, many_wopbs.rs:34-35)
+    const uint64_t *bsk_dev = bsk;
+    void *tmp = nullptr;
+    if (memspace != FHEAES_DEVICE) {
+        HIP_TRY(c, hipMalloc(&tmp, bw * 8));
+        HIP_TRY(c, hipMemcpyAsync(tmp, bsk, bw * 8, hipMemcpyHostToDevice, c->stream));
+        bsk_dev = (const uint64_t *)tmp;
+    }
+    int rc = launch_forward_fourier(c, bsk_dev, bw / FHE_N, c->bskf, FHEAES_STAGE_GGSW_FFT);
+    c->stage_launches[FHEAES_STAGE_GGSW_FFT] = 0; c->stage_units[FHEAES_STAGE_GGSW_FFT] = 0;
+    if (rc == FHEAES_OK) {
+        // offset-digit corrections
+        const uint32_t ncol1 = c->n + 1, rows1 = c->big * c->p.ks_level;
+        hipLaunchKernelGGL(keysum_kernel, dim3((ncol1 + 255) / 256, 1), dim3(256), 0, c->stream, c->ksk, (uint64_t)0, rows1, ncol1,
+                           (uint64_t)(1ull << (c->p.ks_base_log - 1)), c->ksk_init);
+        const uint32_t ncol3 = c->k1 * FHE_N, rows3 = c->big1 * c->p.pfks_level;
+        hipLaunchKernelGGL(keysum_kernel, dim3((ncol3 + 255) / 256, c->k1), dim3(256), 0, c->stream, c->pfpksk, (uint64_t)rows3 * ncol3, rows3, ncol3,
+                           (uint64_t)(1ull << (c->p.pfks_base_log - 1)), c->pfpksk_init);
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (tmp) (void)hipFree(tmp);
+    if (rc != FHEAES_OK) return rc;
+    if (e != hipSuccess) return c->fail(FHEAES_ERR_DEVICE, "key upload: %s", hipGetErrorString(e));
+    HIP_TRY(c, hipGetLastError());
+    if (c->prof) prof_flush(c);
+    c->stage_ms[FHEAES_STAGE_GGSW_FFT] = 0;
+    c->have_keys = true;
+    return FHEAES_OK;
+}
+
+int fheaes_read_bsk_fourier(fheaes_ctx *c, uint32_t i, double *out)
+{
+    TRY(check_keys(c));
+    if (i >= c->n || !out) return c->fail(FHEAES_ERR_INVALID, "bad GGSW index");
+    const size_t words = (size_t)c->p.pbs_level * c->k1 * c->k1 * FHE_N;
+    HIP_TRY(c, hipMemcpyAsync(out, (const double *)c->bskf + (size_t)i * words, words * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return FHEAES_OK;
+}
+
+// ---- stage-by-stage ---------------------------------------------------------------------------
+int fheaes_keyswitch_batch(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t m, uint64_t *lwe_out, int memspace)
+{
+    TRY(check_keys(c));
+    if (!lwe_in || !lwe_out) return c->fail(FHEAES_ERR_INVALID, "null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (memspace == FHEAES_DEVICE) return launch_keyswitch(c, lwe_in, m, lwe_out);
+    Staged s(c);
+    void *din, *dout;
+    TRY(s.in(lwe_in, m * c->big1 * 8, &din));
+    TRY(s.alloc(&dout, m * (c->n + 1) * 8));
+    TRY(launch_keyswitch(c, (const uint64_t *)din, m, (uint64_t *)dout));
+    return s.out(lwe_out, dout, m * (c->n + 1) * 8);
+}
+
+int fheaes_cbs_pbs_batch(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_t level, uint64_t *lwe_out, int memspace)
+{
+    TRY(check_keys(c));
+    if (!lwe_small || !lwe_out) return c->fail(FHEAES_ERR_INVALID, "null pointer");
+    if (level < 1 || level > c->p.cbs_level) return c->fail(FHEAES_ERR_INVALID, "cbs level %u out of range", level);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (memspace == FHEAES_DEVICE) return launch_cbs_pbs(c, lwe_small, m, level, lwe_out);
+    Staged s(c);
+    void *din, *dout;
+    TRY(s.in(lwe_small, m * (c->n + 1) * 8, &din));
+    TRY(s.alloc(&dout, m * c->big1 * 8));
+    TRY(launch_cbs_pbs(c, (const uint64_t *)din, m, level, (uint64_t *)dout));
+    return s.out(lwe_out, dout, m * c->big1 * 8);
+}
+
+int fheaes_pfpks_batch(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t m, uint64_t *ggsw_rows_out, int memspace)
+{
+    TRY(check_keys(c));
+    if (!lwe_in || !ggsw_rows_out) return c->fail(FHEAES_ERR_INVALID, "null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint64_t words = (uint64_t)c->k1 * c->k1 * FHE_N;
+    if (memspace == FHEAES_DEVICE) return launch_pfpks(c, lwe_in, m, ggsw_rows_out, words);
+    Staged s(c);
+    void *din, *dout;
+    TRY(s.in(lwe_in, m * c->big1 * 8, &din));
+    TRY(s.alloc(&dout, m * words * 8));
+    TRY(launch_pfpks(c, (const uint64_t *)din, m, (uint64_t *)dout, words));
+    return s.out(ggsw_rows_out, dout, m * words * 8);
+}
+
+int fheaes_forward_fourier_batch(fheaes_ctx *c, const uint64_t *polys_in, uint64_t polys, double *fourier_out, int memspace)
+{
+    if (!c || !polys_in || !fourier_out) return c ? c->fail(FHEAES_ERR_INVALID, "null pointer") : FHEAES_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (memspace == FHEAES_DEVICE) return launch_forward_fourier(c, polys_in, polys, (double2 *)fourier_out, FHEAES_STAGE_GGSW_FFT);
+    Staged s(c);
+    void *din, *dout;
+    TRY(s.in(polys_in, polys * FHE_N * 8, &din));
+    TRY(s.alloc(&dout, polys * FHE_N * 8));
+    TRY(launch_forward_fourier(c, (const uint64_t *)din, polys, (double2 *)dout, FHEAES_STAGE_GGSW_FFT));
+    return s.out(fourier_out, dout, polys * FHE_N * 8);
+}
+
+int fheaes_vertical_packing_batch(fheaes_ctx *c, const double *ggsw_fourier, uint64_t n_inputs, uint32_t bits, const uint64_t *luts,
+                                  uint32_t n_luts, int lut_per_input, uint64_t *lwe_out, int memspace)
+{
+    if (!c || !ggsw_fourier || !luts || !lwe_out) return c ? c->fail(FHEAES_ERR_INVALID, "null pointer") : FHEAES_ERR_INVALID;
+    if (bits < 1 || bits > 9 || n_luts < 1) return c->fail(FHEAES_ERR_INVALID, "bits must be 1..9 and n_luts >= 1");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (memspace == FHEAES_DEVICE) return launch_vertical_packing(c, (const double2 *)ggsw_fourier, n_inputs, bits, luts, n_luts, lut_per_input, lwe_out);
+    Staged s(c);
+    void *dg, *dl, *dout;
+    const uint64_t gw = (uint64_t)c->k1 * c->k1 * FHE_N;
+    const uint64_t sets = lut_per_input ? n_inputs : 1;
+    TRY(s.in(ggsw_fourier, n_inputs * bits * gw * 8, &dg));
+    TRY(s.in(luts, sets * n_luts * bits * FHE_N * 8, &dl));
+    TRY(s.alloc(&dout, n_inputs * n_luts * bits * c->big1 * 8));
+    TRY(launch_vertical_packing(c, (const double2 *)dg, n_inputs, bits, (const uint64_t *)dl, n_luts, lut_per_input, (uint64_t *)dout));
+    return s.out(lwe_out, dout, n_inputs * n_luts * bits * c->big1 * 8);
+}
+
+// ---- plugin API -------------------------------------------------------------------------------
+int fheaes_wopbs_batch(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t n_inputs, uint32_t bits, const uint64_t *luts, uint32_t n_luts,
+                       int lut_per_input, uint64_t *lwe_out, int memspace)
+{
+    TRY(check_keys(c));
+    if (!lwe_in || !luts || !lwe_out) return c->fail(FHEAES_ERR_INVALID, "null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (memspace == FHEAES_DEVICE) return wopbs_dev(c, lwe_in, n_inputs, bits, luts, n_luts, lut_per_input, lwe_out);
+    if (bits < 1 || bits > 9 || n_luts < 1) return c->fail(FHEAES_ERR_INVALID, "bits must be 1..9 and n_luts >= 1");
+    Staged s(c);
+    void *din, *dl, *dout;
+    const uint64_t sets = lut_per_input ? n_inputs : 1;
+    TRY(s.in(lwe_in, n_inputs * bits * c->big1 * 8, &din));
+    TRY(s.in(luts, sets * n_luts * bits * FHE_N * 8, &dl));
+    TRY(s.alloc(&dout, n_inputs * n_luts * bits * c->big1 * 8));
+    TRY(wopbs_dev(c, (const uint64_t *)din, n_inputs, bits, (const uint64_t *)dl, n_luts, lut_per_input, (uint64_t *)dout));
+    return s.out(lwe_out, dout, n_inputs * n_luts * bits * c->big1 * 8);
+}
+
+static int many_sbox_dev(fheaes_ctx *c, const uint64_t *bytes, uint64_t n_bytes, int set, uint64_t *out)
+{
+    return wopbs_dev(c, bytes, n_bytes, 8, c->lutset_d[set], (uint32_t)c->lutset_n[set], 0, out);
+}
+
+int fheaes_many_sbox(fheaes_ctx *c, const uint64_t *bytes, uint64_t n_bytes, int inv, uint64_t *out, int memspace)
+{
+    TRY(check_keys(c));
+    if (!bytes || !out) return c->fail(FHEAES_ERR_INVALID, "null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int set = inv ? LUTSET_DEC_MUL : LUTSET_ENC_ROUND;
+    if (memspace == FHEAES_DEVICE) return many_sbox_dev(c, bytes, n_bytes, set, out);
+    Staged s(c);
+    void *din, *dout;
+    const uint64_t bw = 8ull * c->big1;
+    TRY(s.in(bytes, n_bytes * bw * 8, &din));
+    TRY(s.alloc(&dout, n_bytes * c->lutset_n[set] * bw * 8));
+    TRY(many_sbox_dev(c, (const uint64_t *)din, n_bytes, set, (uint64_t *)dout));
+    return s.out(out, dout, n_bytes * c->lutset_n[set] * bw * 8);
+}
+
+int fheaes_sbox(fheaes_ctx *c, uint64_t *bytes, uint64_t n_bytes, int inv, int memspace)
+{
+    TRY(check_keys(c));
+    if (!bytes) return c->fail(FHEAES_ERR_INVALID, "null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int set = inv ? LUTSET_INV_SBOX : LUTSET_SBOX;
+    const uint64_t bw = 8ull * c->big1;
+    if (memspace == FHEAES_DEVICE) {
+        TRY(ensure(c, c->ws_vp, n_bytes * bw * 8));
+        TRY(many_sbox_dev(c, bytes, n_bytes, set, (uint64_t *)c->ws_vp.p));
+        HIP_TRY(c, hipMemcpyAsync(bytes, c->ws_vp.p, n_bytes * bw * 8, hipMemcpyDeviceToDevice, c->stream));
+        return FHEAES_OK;
+    }
+    Staged s(c);
+    void *din, *dout;
+    TRY(s.in(bytes, n_bytes * bw * 8, &din));
+    TRY(s.alloc(&dout, n_bytes * bw * 8));
+    TRY(many_sbox_dev(c, (const uint64_t *)din, n_bytes, set, (uint64_t *)dout));
+    return s.out(bytes, dout, n_bytes * bw * 8);
+}
+
+// ---- Server API -------------------------------------------------------------------------------
+static int aes_encrypt_dev(fheaes_ctx *c, const uint64_t *rk, uint64_t *state, uint64_t n_blocks)
+{
+    const uint64_t bw = 8ull * c->big1, sw = 16 * bw, nbytes = 16 * n_blocks;
+    TRY(ensure(c, c->ws_vp, nbytes * 3 * bw * 8));
+    uint64_t *vp = (uint64_t *)c->ws_vp.p;
+    const GatherTable t_round = table_enc_round(), t_shift = table_shift_rows(false);
+    TRY(launch_add_bcast(c, state, rk, sw, n_blocks));                                   // server.rs:42
+    for (int round = 1; round < 10; ++round) {                                           // server.rs:44-57
+        TRY(many_sbox_dev(c, state, nbytes, LUTSET_ENC_ROUND, vp));
+        TRY(launch_gather(c, vp, 3, rk + (uint64_t)round * sw, state, n_blocks, t_round));
+    }
+    TRY(many_sbox_dev(c, state, nbytes, LUTSET_SBOX, vp));                               // server.rs:59-63
+    TRY(launch_gather(c, vp, 1, rk + 10ull * sw, state, n_blocks, t_shift));
+    return FHEAES_OK;
+}
+
+static int aes_decrypt_dev(fheaes_ctx *c, const uint64_t *rk, uint64_t *state, uint64_t n_blocks)
+{
+    const uint64_t bw = 8ull * c->big1, sw = 16 * bw, nbytes = 16 * n_blocks;
+    TRY(ensure(c, c->ws_vp, nbytes * 4 * bw * 8));
+    uint64_t *vp = (uint64_t *)c->ws_vp.p;
+    const GatherTable t_inv = table_shift_rows(true), t_mix = table_dec_mix();
+    TRY(launch_add_bcast(c, state, rk + 10ull * sw, sw, n_blocks));                      // server.rs:70
+    for (int round = 10; round >= 2; --round) {                                          // server.rs:72-96
+        // inv_shift_rows commutes with the bytewise S-Box: INV_SBOX first, then the permutation + round key
+        TRY(many_sbox_dev(c, state, nbytes, LUTSET_INV_SBOX, vp));
+        TRY(launch_gather(c, vp, 1, rk + (uint64_t)(round - 1) * sw, state, n_blocks, t_inv));
+        TRY(many_sbox_dev(c, state, nbytes, LUTSET_DEC_MUL, vp));
+        TRY(launch_gather(c, vp, 4, nullptr, state, n_blocks, t_mix));
+    }
+    TRY(many_sbox_dev(c, state, nbytes, LUTSET_INV_SBOX, vp));                           // server.rs:98-104
+    TRY(launch_gather(c, vp, 1, rk, state, n_blocks, t_inv));
+    return FHEAES_OK;
+}
+
+static int aes_crypt(fheaes_ctx *c, const uint64_t *round_keys, uint64_t *state, uint64_t n_blocks, int memspace, bool dec)
+{
+    TRY(check_keys(c));
+    if (!round_keys || !state) return c->fail(FHEAES_ERR_INVALID, "null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (memspace == FHEAES_DEVICE) return dec ? aes_decrypt_dev(c, round_keys, state, n_blocks) : aes_encrypt_dev(c, round_keys, state, n_blocks);
+    Staged s(c);
+    void *drk, *dst;
+    const uint64_t sw = 16ull * 8 * c->big1;
+    TRY(s.in(round_keys, 11 * sw * 8, &drk));
+    TRY(s.in(state, n_blocks * sw * 8, &dst));
+    TRY(dec ? aes_decrypt_dev(c, (const uint64_t *)drk, (uint64_t *)dst, n_blocks) : aes_encrypt_dev(c, (const uint64_t *)drk, (uint64_t *)dst, n_blocks));
+    return s.out(state, dst, n_blocks * sw * 8);
+}
+
+int fheaes_aes_encrypt(fheaes_ctx *c, const uint64_t *round_keys, uint64_t *state, uint64_t n_blocks, int memspace)
+{
+    return aes_crypt(c, round_keys, state, n_blocks, memspace, false);
+}
+
+int fheaes_aes_decrypt(fheaes_ctx *c, const uint64_t *round_keys, uint64_t *state, uint64_t n_blocks, int memspace)
+{
+    return aes_crypt(c, round_keys, state, n_blocks, memspace, true);
+}
+
+static int key_expansion_dev(fheaes_ctx *c, const uint64_t *key, uint64_t *w)
+{
+    static const uint8_t RCON[10] = {0x01, 0x02, 0x04, 0x08, 0x10, 0x20, 0x40, 0x80, 0x1B, 0x36};
+    const uint64_t bw = 8ull * c->big1, ww = 4 * bw;
+    TRY(ensure(c, c->ws_tmp_a, ww * 8));
+    TRY(ensure(c, c->ws_tmp_b, ww * 8));
+    uint64_t *ta = (uint64_t *)c->ws_tmp_a.p, *tb = (uint64_t *)c->ws_tmp_b.p;
+    HIP_TRY(c, hipMemcpyAsync(w, key, 4 * ww * 8, hipMemcpyDeviceToDevice, c->stream));             // server.rs:122-128
+    for (int i = 4; i < 44; ++i) {                                                                  // server.rs:131-155
+        const uint64_t *prev = w + (uint64_t)(i - 1) * ww;
+        if (i % 4 == 0) {
+            for (int j = 0; j < 4; ++j)                                                             // fhe_rot_word
+                HIP_TRY(c, hipMemcpyAsync(ta + (uint64_t)j * bw, prev + (uint64_t)((j + 1) & 3) * bw, bw * 8, hipMemcpyDeviceToDevice, c->stream));
+            TRY(many_sbox_dev(c, ta, 4, LUTSET_SBOX, tb));                                          // fhe_sub_word
+            hipLaunchKernelGGL(add_const_byte_kernel, dim3(1), dim3(64), 0, c->stream, tb, c->big1, (uint32_t)RCON[i / 4 - 1]);
+            HIP_TRY(c, hipGetLastError());
+            TRY(launch_add2(c, ta, tb, w + (uint64_t)(i - 4) * ww, ww));
+        } else {
+            TRY(launch_add2(c, ta, prev, w + (uint64_t)(i - 4) * ww, ww));
+        }
+        TRY(many_sbox_dev(c, ta, 4, LUTSET_IDENTITY, w + (uint64_t)i * ww));                        // refresh, server.rs:150
+    }
+    return FHEAES_OK;
+}
+
+int fheaes_aes_key_expansion(fheaes_ctx *c, const uint64_t *key, uint64_t *round_keys, int memspace)
+{
+    TRY(check_keys(c));
+    if (!key || !round_keys) return c->fail(FHEAES_ERR_INVALID, "null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (memspace == FHEAES_DEVICE) return key_expansion_dev(c, key, round_keys);
+    Staged s(c);
+    void *dk, *dw;
+    const uint64_t sw = 16ull * 8 * c->big1;
+    TRY(s.in(key, sw * 8, &dk));
+    TRY(s.alloc(&dw, 11 * sw * 8));
+    TRY(key_expansion_dev(c, (const uint64_t *)dk, (uint64_t *)dw));
+    return s.out(round_keys, dw, 11 * sw * 8);
+}
+
+static int add_scalar_dev(fheaes_ctx *c, uint64_t *state, uint64_t n_blocks, const uint64_t *counters)
+{
+    const uint32_t lw = c->big1;
+    // counter bytes, MSB first (server.rs:174-178): addend[byte][blk]
+    std::vector<uint8_t> add(16 * n_blocks);
+    for (uint64_t b = 0; b < n_blocks; ++b) {
+        uint64_t hi = counters[2 * b], lo = counters[2 * b + 1];
+        for (int j = 0; j < 8; ++j) { add[(15 - j) * n_blocks + b] = (uint8_t)(lo >> (8 * j)); add[(7 - j) * n_blocks + b] = (uint8_t)(hi >> (8 * j)); }
+    }
+    TRY(ensure(c, c->ws_misc, 16 * n_blocks + n_blocks * lw * 8 + 64));
+    uint8_t *add_d = (uint8_t *)c->ws_misc.p;
+    uint64_t *carry = (uint64_t *)((uint8_t *)c->ws_misc.p + ((16 * n_blocks + 63) / 64) * 64);
+    HIP_TRY(c, hipMemcpyAsync(add_d, add.data(), add.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // `add` is a local
+    TRY(ensure(c, c->ws_tmp_a, n_blocks * 9ull * lw * 8));
+    TRY(ensure(c, c->ws_tmp_b, n_blocks * 2ull * 9 * lw * 8));
+    TRY(ensure(c, c->ws_luts, n_blocks * 2ull * 9 * FHE_N * 8));
+    uint64_t *in9 = (uint64_t *)c->ws_tmp_a.p, *res = (uint64_t *)c->ws_tmp_b.p, *luts = (uint64_t *)c->ws_luts.p;
+    for (int byte = 15; byte >= 0; --byte) {
+        const uint32_t bits = byte == 15 ? 8 : 9;
+        dim3 g1((bits * lw + 255) / 256, (unsigned)n_blocks);
+        hipLaunchKernelGGL(pack9_kernel, g1, dim3(256), 0, c->stream, (const uint64_t *)state, (const uint64_t *)carry, in9, (uint32_t)byte, lw, n_blocks, bits);
+        hipLaunchKernelGGL(counter_lut_kernel, dim3((2 * bits * FHE_N + 255) / 256, (unsigned)n_blocks), dim3(256), 0, c->stream, luts,
+                           (const uint8_t *)(add_d + (size_t)byte * n_blocks), bits, n_blocks);
+        HIP_TRY(c, hipGetLastError());
+        TRY(wopbs_dev(c, in9, n_blocks, bits, luts, 2, 1, res));
+        hipLaunchKernelGGL(unpack_sum_carry_kernel, dim3((9 * lw + 255) / 256, (unsigned)n_blocks), dim3(256), 0, c->stream, (const uint64_t *)res, bits, state, carry,
+                           (uint32_t)byte, lw, n_blocks);
+        HIP_TRY(c, hipGetLastError());
+    }
+    return FHEAES_OK;
+}
+
+int fheaes_add_scalar(fheaes_ctx *c, uint64_t *state, uint64_t n_blocks, const uint64_t *counters_hi_lo, int memspace)
+{
+    TRY(check_keys(c));
+    if (!state || !counters_hi_lo) return c->fail(FHEAES_ERR_INVALID, "null pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_blocks == 0) return FHEAES_OK;
+    if (memspace == FHEAES_DEVICE) return add_scalar_dev(c, state, n_blocks, counters_hi_lo);
+    Staged s(c);
+    void *dst;
+    const uint64_t sw = 16ull * 8 * c->big1;
+    TRY(s.in(state, n_blocks * sw * 8, &dst));
+    TRY(add_scalar_dev(c, (uint64_t *)dst, n_blocks, counters_hi_lo));
+    return s.out(state, dst, n_blocks * sw * 8);
+}
+
+// ---- measurement ------------------------------------------------------------------------------
+int fheaes_profile_enable(fheaes_ctx *c, int on)
+{
+    if (!c) return FHEAES_ERR_INVALID;
+    if (!on && c->prof) TRY(prof_flush(c));
+    c->prof = on != 0;
+    return FHEAES_OK;
+}
+
+int fheaes_profile_reset(fheaes_ctx *c)
+{
+    if (!c) return FHEAES_ERR_INVALID;
+    TRY(prof_flush(c));
+    for (int s = 0; s < FHEAES_STAGE_COUNT; ++s) { c->stage_ms[s] = 0; c->stage_launches[s] = 0; c->stage_units[s] = 0; }
+    return FHEAES_OK;
+}
+
+int fheaes_profile_read(fheaes_ctx *c, int stage, double *total_ms, uint64_t *launches, uint64_t *units)
+{
+    if (!c || stage < 0 || stage >= FHEAES_STAGE_COUNT) return FHEAES_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    TRY(prof_flush(c));
+    if (total_ms) *total_ms = c->stage_ms[stage];
+    if (launches) *launches = c->stage_launches[stage];
+    if (units) *units = c->stage_units[stage];
+    return FHEAES_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,257 @@
+// kern_extprod.h -- the external-product kernels:
+//   K2  blind rotation of the circuit-bootstrap PBS + sample extract   
+//   K5  vertical packing = CMUX blind rotation over the LUT + sample extract (8 a15)
+//   K4  torus polynomials -> Fourier domain (BSK upload, ggsw.fill_with_forward_fourier, 8 a14)
+//
+// One 256-thread workgroup = 16 lane-groups of 16.  Group g < R*K1 owns polynomial p = g % K1 of
+// ciphertext r = g / K1 of the workgroup's R ciphertexts: its 512 accumulator coefficients live
+// in that group's registers for the whole rotation (coefficients 16a+b and 256+16a+b in lane b).
+// Per iteration and per decomposition level the groups transform their digit polynomials
+// (fft_dev.h) into the LDS tile ring, then ALL 256 threads switch roles: thread t owns Fourier
+// point t and multiplies the R x K1 transformed digits with the K1 x K1 GGSW entries streamed from
+// HBM/L2, so each 16-byte key element fetched is used by R ciphertexts.  After the last level the
+// products go back through LDS to the owning groups for the inverse transform.
+#pragma once
+#include "fft_dev.h"
+
+#define EP_THREADS 256
+#define EP_GROUPS 16
+#define EP_LDS_DOUBLES (EP_GROUPS * GROUP_TILE_DOUBLES + 2 * 2 * FHE_H)
+
+struct ExtProdArgs {
+    // common
+    const double2 *ggsw;        // PBS: BSK Fourier [n][L][K1][K1][256]; VP: [n_inputs][bits][L][K1][K1][256]
+    const double2 *psi;         // [256] psi^j
+    const double2 *tw;          // [256] tw[k1*16+b] = w256^(k1*b)
+    FftConsts fc;
+    uint64_t *out;              // PBS: [m][big+1]; VP: [n_inputs][n_luts][bits][big+1]
+    uint64_t count;             // PBS: ciphertexts m; VP: n_inputs * n_luts * bits instances
+    uint32_t iters;             // PBS: n; VP: bits
+    // PBS mode
+    const uint64_t *lwe_in;     // [m][n+1]
+    uint64_t tv_const;          // every coefficient of the test vector
+    uint64_t body_shift;        // added to the input body before the modulus switch (2^62)
+    uint64_t post_add;          // added to the output body
+    // VP mode
+    const uint64_t *luts;       // [n_sets][n_luts][bits][512]
+    uint32_t n_luts;
+    uint32_t lut_per_input;
+    uint32_t inst_per_input;    // n_luts * bits
+    uint32_t wg_per_input;      // ceil(inst_per_input / R)
+};
+
+template <int K1, int LEVELS, int BASE_LOG, int R, bool VP>
+__global__ __launch_bounds__(EP_THREADS, 2) void extprod_rotate_kernel(const ExtProdArgs A)
+{
+    static_assert(R * K1 <= EP_GROUPS, "too many polynomials for 16 lane groups");
+    __shared__ __attribute__((aligned(16))) double lds[EP_LDS_DOUBLES];
+    double2 *psi = reinterpret_cast<double2 *>(lds + EP_GROUPS * GROUP_TILE_DOUBLES);
+    double2 *tw = psi + FHE_H;
+
+    const int tid = threadIdx.x;
+    const int g = tid >> 4, b = tid & 15;
+    const bool owner = g < R * K1;
+    const int r_own = owner ? g / K1 : R - 1;
+    const int p_own = owner ? g % K1 : K1 - 1;
+    double *tile = lds + g * GROUP_TILE_DOUBLES;
+    const FftConsts fc = A.fc;
+
+    psi[tid] = A.psi[tid];
+    tw[tid] = A.tw[tid];
+
+    // ---- which ciphertext / instance does this group work on -------------------------------
+    uint64_t inst;            // PBS: ciphertext index; VP: global instance index
+    uint64_t input = 0;       // VP: which radix input (selects the GGSW list)
+    bool valid;
+    if (!VP) {
+        inst = (uint64_t)blockIdx.x * R + r_own;
+        valid = inst < A.count;
+        if (!valid) inst = A.count - 1;
+    } else {
+        input = blockIdx.x / A.wg_per_input;
+        uint32_t local = (blockIdx.x % A.wg_per_input) * R + r_own;
+        valid = local < A.inst_per_input;
+        if (!valid) local = A.inst_per_input - 1;
+        inst = input * A.inst_per_input + local;
+    }
+
+    // ---- accumulator init --------------------------------------------------------------------
+    uint64_t lo[16], hi[16];
+    const uint64_t *lwe = nullptr;
+    if (!VP) {
+        lwe = A.lwe_in + inst * (uint64_t)(A.iters + 1);
+        const int bt = mod_switch_1024(lwe[A.iters] + A.body_shift);
+        const int t = (1024 - bt) & 1023;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            int j0 = 16 * a + b, j1 = j0 + 256;
+            int e0 = ((j0 - t) & 511) + t, e1 = ((j1 - t) & 511) + t;
+            uint64_t v0 = ((e0 >> 9) & 1) ? (uint64_t)0 - A.tv_const : A.tv_const;
+            uint64_t v1 = ((e1 >> 9) & 1) ? (uint64_t)0 - A.tv_const : A.tv_const;
+            lo[a] = (p_own == K1 - 1) ? v0 : 0;
+            hi[a] = (p_own == K1 - 1) ? v1 : 0;
+        }
+    } else {
+        uint64_t local = inst % A.inst_per_input;
+        uint64_t set = A.lut_per_input ? input : 0;
+        const uint64_t *lut = A.luts + (set * A.inst_per_input + local) * FHE_N;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            lo[a] = (p_own == K1 - 1) ? lut[16 * a + b] : 0;
+            hi[a] = (p_own == K1 - 1) ? lut[256 + 16 * a + b] : 0;
+        }
+    }
+    __syncthreads();   // tables visible
+
+    const size_t ggsw_stride = (size_t)LEVELS * K1 * K1 * FHE_H;   // double2 elements per GGSW
+
+    for (uint32_t it = 0; it < A.iters; ++it) {
+        int t;
+        const double2 *G;
+        if (!VP) {
+            t = mod_switch_1024(lwe[it]);
+            G = A.ggsw + (size_t)it * ggsw_stride;
+        } else {
+            t = (1024 - (1 << it)) & 1023;
+            G = A.ggsw + ((size_t)input * A.iters + it) * ggsw_stride;
+        }
+
+        // ---- d = acc * X^t - acc, first decomposition level -----------------------------------
+        uint64_t *stage = reinterpret_cast<uint64_t *>(tile);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            stage[16 * a + b] = lo[a];
+            stage[256 + 16 * a + b] = hi[a];
+        }
+        wave_lds_sync();
+        uint32_t st_lo[16], st_hi[16];
+        double xr[16], xi[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            int j0 = 16 * a + b, j1 = j0 + 256;
+            int s0 = (j0 - t) & 511, s1 = (j1 - t) & 511;
+            uint64_t v0 = stage[s0], v1 = stage[s1];
+            if (((s0 + t) >> 9) & 1) v0 = (uint64_t)0 - v0;
+            if (((s1 + t) >> 9) & 1) v1 = (uint64_t)0 - v1;
+            v0 -= lo[a]; v1 -= hi[a];
+            xr[a] = (double)decompose_first<BASE_LOG, LEVELS>(v0, st_lo[a]);
+            xi[a] = (double)decompose_first<BASE_LOG, LEVELS>(v1, st_hi[a]);
+        }
+        wave_lds_sync();
+
+        double fr[R][K1], fi[R][K1];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < K1; ++c) { fr[r][c] = 0.0; fi[r][c] = 0.0; }
+
+#pragma unroll 1
+        for (int l = LEVELS - 1; l >= 0; --l) {
+            if (l != LEVELS - 1) {
+#pragma unroll
+                for (int a = 0; a < 16; ++a) {
+                    xr[a] = (double)decompose_next<BASE_LOG>(st_lo[a]);
+                    xi[a] = (double)decompose_next<BASE_LOG>(st_hi[a]);
+                }
+            }
+            nega_fwd(xr, xi, psi, tw, tile, b, fc);
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                double2 v; v.x = xr[k2]; v.y = xi[k2];
+                *reinterpret_cast<double2 *>(tile + 2 * (b + 16 * k2)) = v;
+            }
+            __syncthreads();
+            // ---- multiply-accumulate role: thread tid owns Fourier point tid ------------------
+            const double2 *Gl = G + (size_t)l * K1 * K1 * FHE_H + tid;
+#pragma unroll
+            for (int p = 0; p < K1; ++p) {
+                double2 bv[K1];
+#pragma unroll
+                for (int c = 0; c < K1; ++c) bv[c] = Gl[(size_t)(p * K1 + c) * FHE_H];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    double2 d = *reinterpret_cast<const double2 *>(lds + (r * K1 + p) * GROUP_TILE_DOUBLES + 2 * tid);
+#pragma unroll
+                    for (int c = 0; c < K1; ++c) {
+                        fr[r][c] = __builtin_fma(d.x, bv[c].x, fr[r][c]);
+                        fr[r][c] = __builtin_fma(-d.y, bv[c].y, fr[r][c]);
+                        fi[r][c] = __builtin_fma(d.x, bv[c].y, fi[r][c]);
+                        fi[r][c] = __builtin_fma(d.y, bv[c].x, fi[r][c]);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- products back to the owning groups, inverse transform, accumulate ----------------
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < K1; ++c) {
+                double2 v; v.x = fr[r][c]; v.y = fi[r][c];
+                *reinterpret_cast<double2 *>(lds + (r * K1 + c) * GROUP_TILE_DOUBLES + 2 * tid) = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (b + 16 * k2));
+            xr[k2] = v.x; xi[k2] = v.y;
+        }
+        wave_lds_sync();
+        nega_inv(xr, xi, psi, tw, tile, b, fc);
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            lo[a] += torus_from_double(xr[a]);
+            hi[a] += torus_from_double(xi[a]);
+        }
+    }
+
+    // ---- sample extract coefficient 0 ---------------------------------------------
+    if (owner && valid) {
+        const uint64_t big = (uint64_t)(K1 - 1) * FHE_N;
+        uint64_t *o = A.out + inst * (big + 1);
+        if (p_own < K1 - 1) {
+            uint64_t *om = o + (uint64_t)p_own * FHE_N;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                int j0 = 16 * a + b, j1 = j0 + 256;
+                if (j0 == 0) om[0] = lo[a]; else om[FHE_N - j0] = (uint64_t)0 - lo[a];
+                om[FHE_N - j1] = (uint64_t)0 - hi[a];
+            }
+        } else if (b == 0) {
+            o[big] = lo[0] + (VP ? 0 : A.post_add);
+        }
+    }
+}
+
+// K4: `polys` torus polynomials (natural u64[512]) -> Fourier double2[256], one polynomial per lane group
+__global__ __launch_bounds__(EP_THREADS) void forward_fourier_kernel(const uint64_t *in, double2 *out, uint64_t polys,
+                                                                     const double2 *psi_g, const double2 *tw_g, FftConsts fc)
+{
+    __shared__ __attribute__((aligned(16))) double lds[EP_LDS_DOUBLES];
+    double2 *psi = reinterpret_cast<double2 *>(lds + EP_GROUPS * GROUP_TILE_DOUBLES);
+    double2 *tw = psi + FHE_H;
+    const int tid = threadIdx.x, g = tid >> 4, b = tid & 15;
+    double *tile = lds + g * GROUP_TILE_DOUBLES;
+    psi[tid] = psi_g[tid];
+    tw[tid] = tw_g[tid];
+    __syncthreads();
+    for (uint64_t base = (uint64_t)blockIdx.x * EP_GROUPS; base < polys; base += (uint64_t)gridDim.x * EP_GROUPS) {
+        uint64_t q = base + g;
+        bool valid = q < polys;
+        if (!valid) q = polys - 1;
+        const uint64_t *p = in + q * FHE_N;
+        double xr[16], xi[16];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            xr[a] = double_from_torus(p[16 * a + b]);
+            xi[a] = double_from_torus(p[256 + 16 * a + b]);
+        }
+        nega_fwd(xr, xi, psi, tw, tile, b, fc);
+        if (valid) {
+            double2 *o = out + q * FHE_H;
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) { double2 v; v.x = xr[k2]; v.y = xi[k2]; o[b + 16 * k2] = v; }
+        }
+    }
+}

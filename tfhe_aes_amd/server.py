@@ -1,0 +1,125 @@
+"""``Server`` and the S-Box front end: the reference's operator API for the hot path.
+
+Same names, argument meaning and error behaviour as
+  /root/reference/src/server/server.rs        Server::{new, aes_encrypt, aes_decrypt, aes_key_expansion, add_scalar}
+  /root/reference/src/server/sbox/sbox.rs     sbox, many_sbox, mul2 .. mul14
+  /root/reference/src/server/sbox/many_wopbs.rs  many_wopbs_without_padding
+  /root/reference/src/server/sbox/gen_lut.rs  gen_lut
+but batched (a leading block axis) and over flat uint64 arrays:
+  byte = [8][kN+1], state = [16][8][kN+1], round keys = [11][16][8][kN+1].
+Arrays may be numpy (host; staged through HBM by the engine) or torch CUDA tensors (resident,
+asynchronous on the engine's stream).  All compute happens in libfheaes.so (HIP); this module
+only allocates outputs and forwards.  README.md:57-59 of the reference spells the methods
+``aes_encryption`` / ``aes_decryption``; both spellings are provided.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native
+from .aes_clear import INV_SBOX, SBOX, mul2, mul3, mul9, mul11, mul13, mul14  # noqa: F401  (re-exported like sbox.rs)
+from .client import ServerKeys
+from .params import WopbsParameters
+
+
+def gen_lut(message_mod: int, carry_mod: int, poly_size: int, nb_block: int, f) -> np.ndarray:
+    """gen_lut.rs:9-42.  Returns [nb_block][poly_size] uint64, entry = output bit << 63."""
+    if message_mod != 2 or carry_mod != 1:
+        raise ValueError("the path uses message_modulus 2, carry_modulus 1 (client.rs:53-54)")
+    if poly_size != 512 or not 1 <= nb_block <= 9:
+        raise ValueError("polynomial_size must be 512 and nb_block in 1..9")
+    table = np.array([int(f(x)) for x in range(1 << nb_block)], dtype=np.uint64)
+    return _native.gen_lut(nb_block, table)
+
+
+def _empty_like(ref, shape):
+    if isinstance(ref, np.ndarray):
+        return np.empty(shape, dtype=np.uint64)
+    import torch
+
+    return torch.empty(shape, dtype=torch.int64, device=ref.device)
+
+
+def _to_space(arr: np.ndarray, ref):
+    if isinstance(ref, np.ndarray):
+        return np.ascontiguousarray(arr, dtype=np.uint64)
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).view(np.int64)).to(ref.device)
+
+
+class Server:
+    """``Server::new`` (server.rs:32): takes the evaluation keys by value; the engine copies them to HBM."""
+
+    def __init__(self, keys: ServerKeys, device: int = 0, engine: _native.Engine | None = None):
+        self.params: WopbsParameters = keys.params
+        self.engine = engine or _native.Engine(keys.params, device)
+        self.engine.upload_keys(np.ascontiguousarray(keys.ksk), np.ascontiguousarray(keys.bsk), np.ascontiguousarray(keys.pfpksk))
+
+    # ---- S-Box front end --------------------------------------------------------
+    def many_wopbs_without_padding(self, ct_in, luts):
+        """many_wopbs.rs:31: ct_in [n][bits][kN+1]; luts: list of gen_lut tables [bits][512] (shared by
+        all inputs) or an array [n][n_luts][bits][512] (one set per input).  Returns [n][n_luts][bits][kN+1]."""
+        n, bits = int(ct_in.shape[0]), int(ct_in.shape[1])
+        if isinstance(luts, (list, tuple)):
+            lut_arr = np.stack([np.asarray(l, dtype=np.uint64) for l in luts])[None]
+            per_input = False
+        else:
+            lut_arr = np.asarray(luts) if isinstance(luts, np.ndarray) else luts
+            per_input = lut_arr.ndim == 4 and lut_arr.shape[0] == n and n > 1
+            if lut_arr.ndim == 3:
+                lut_arr = lut_arr[None]
+        n_luts = int(lut_arr.shape[1])
+        if int(lut_arr.shape[2]) != bits or int(lut_arr.shape[3]) != 512:
+            raise ValueError("LUT shape does not match the input radix width")
+        lut_dev = _to_space(lut_arr, ct_in) if isinstance(lut_arr, np.ndarray) else lut_arr
+        out = _empty_like(ct_in, (n, n_luts, bits, self.params.big1))
+        self.engine.wopbs_batch(ct_in, n, bits, lut_dev, n_luts, per_input, out)
+        return out
+
+    def sbox(self, ct_in, inv: bool):
+        """sbox.rs:46, in place over a batch of bytes [n][8][kN+1]."""
+        self.engine.sbox(ct_in, int(ct_in.shape[0]), inv)
+        return ct_in
+
+    def many_sbox(self, ct_in, inv: bool):
+        """sbox.rs:68: [n][8][kN+1] -> [n][L][8][kN+1]; L=3 (S, 2S, 3S) or 4 (9x, 11x, 13x, 14x)."""
+        n = int(ct_in.shape[0])
+        out = _empty_like(ct_in, (n, 4 if inv else 3, 8, self.params.big1))
+        self.engine.many_sbox(ct_in, n, inv, out)
+        return out
+
+    # ---- Server API -------------------------------------------------------------
+    def aes_key_expansion(self, key):
+        """server.rs:107: key [16][8][kN+1] -> round keys [11][16][8][kN+1]."""
+        rk = _empty_like(key, (11, 16, 8, self.params.big1))
+        self.engine.aes_key_expansion(key, rk)
+        return rk
+
+    def aes_encrypt(self, encrypted_round_keys, state):
+        """server.rs:39, in place.  state [16][8][kN+1] or a batch [B][16][8][kN+1]."""
+        n_blocks = 1 if state.ndim == 3 else int(state.shape[0])
+        self.engine.aes_encrypt(encrypted_round_keys, state, n_blocks)
+        return state
+
+    def aes_decrypt(self, encrypted_round_keys, state):
+        """server.rs:67, in place."""
+        n_blocks = 1 if state.ndim == 3 else int(state.shape[0])
+        self.engine.aes_decrypt(encrypted_round_keys, state, n_blocks)
+        return state
+
+    def add_scalar(self, state, i):
+        """server.rs:172, in place.  ``i`` is one integer, or one per block of a batched state."""
+        n_blocks = 1 if state.ndim == 3 else int(state.shape[0])
+        counters = [i] * n_blocks if isinstance(i, int) else list(i)
+        if len(counters) != n_blocks:
+            raise ValueError("one counter per block expected")
+        self.engine.add_scalar(state, n_blocks, counters)
+        return state
+
+    # README.md:57-59 spellings
+    aes_encryption = aes_encrypt
+    aes_decryption = aes_decrypt
+
+    def synchronize(self):
+        self.engine.synchronize()
