@@ -1,0 +1,138 @@
+"""The plugin / Server API on the MI355X (through the C ABI and the Python mirror of the reference's
+interface) against the oracle, the golden hashes and AES known answers."""
+import numpy as np
+import pytest
+
+from conftest import Kit, sha
+from oracle import oracle as orc
+from tfhe_aes_amd import PARAM_TOY, aes_clear
+from tfhe_aes_amd.server import Server, gen_lut
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def toy_server(toy):
+    return Server(toy.keys, device=0, engine=toy.engine())
+
+
+@pytest.mark.parametrize("n_luts_set", [orc.LUTSET_SBOX, orc.LUTSET_ENC_ROUND, orc.LUTSET_DEC_MUL])
+def test_many_wopbs_8bit(toy, toy_server, n_luts_set):
+    vals = [0x00, 0x53, 0xFF, 0xA7, 0x10]
+    x = toy.client.encrypt_bytes(vals)
+    luts = orc.build_lutset(n_luts_set)
+    got = toy_server.many_wopbs_without_padding(x, list(luts))
+    assert np.array_equal(got, toy.oracle.wopbs_batch(x, luts))
+
+
+def test_many_wopbs_9bit_with_per_input_luts(toy, toy_server):
+    """the shape add_scalar uses: 9 blocks (8 bits + carry), two 9->9 LUTs that differ per input (server.rs:216-252)"""
+    c, p = toy.client, toy.params
+    rng = np.random.default_rng(9)
+    n = 3
+    bits = rng.integers(0, 2, (n, 9)).astype(np.uint8)
+    x = c.encrypt_bits(bits)
+    luts = np.stack([np.stack([gen_lut(2, 1, 512, 9, lambda v, a=a: ((v & 0xFF) + (v >> 8) + a) % 256),
+                               gen_lut(2, 1, 512, 9, lambda v, a=a: 1 if (v & 0xFF) + (v >> 8) + a > 255 else 0)])
+                     for a in (3, 200, 255)])
+    got = toy_server.many_wopbs_without_padding(x, luts)
+    want = toy.oracle.wopbs_batch(x, luts, lut_per_input=True)
+    assert np.array_equal(got, want)
+    dec = c.decrypt_bits(got)
+    for i, a in enumerate((3, 200, 255)):
+        v = int(sum(int(bits[i, j]) << j for j in range(9)))
+        s = (v & 0xFF) + (v >> 8) + a
+        assert int(sum(int(dec[i, 0, j]) << j for j in range(8))) == s % 256 and int(dec[i, 1, 0]) == (1 if s > 255 else 0)
+
+
+def test_sbox_and_many_sbox(toy, toy_server):
+    c = toy.client
+    vals = [0x3C, 0x00, 0x80]
+    x = c.encrypt_bytes(vals)
+    ms = toy_server.many_sbox(x, inv=False)
+    assert np.array_equal(ms, toy.oracle.wopbs_batch(x, orc.build_lutset(orc.LUTSET_ENC_ROUND)))
+    mi = toy_server.many_sbox(x, inv=True)
+    assert np.array_equal(mi, toy.oracle.wopbs_batch(x, orc.build_lutset(orc.LUTSET_DEC_MUL)))
+    y = x.copy()
+    toy_server.sbox(y, inv=False)
+    assert np.array_equal(y, ms[:, 0])                      # sbox == first LUT of many_sbox (sbox.rs:52 vs :79)
+    assert list(c.decrypt_bytes(y)) == [aes_clear.SBOX[v] for v in vals]
+    toy_server.sbox(y, inv=True)
+    assert list(c.decrypt_bytes(y)) == vals
+
+
+def test_aes_pipeline_bit_exact_and_golden(golden):
+    """a fresh kit replays the golden sequence: HIP output hashes == the oracle's committed hashes"""
+    g = golden["oracle_toy"]
+    kit = Kit(PARAM_TOY, seed=g["seed"])
+    c, p = kit.client, kit.params
+    srv = Server(kit.keys, device=0)
+    x = c.encrypt_bytes([0x00, 0x53, 0xFF, 0xA7, 0x10])
+    assert sha(x.reshape(-1, p.big1)) == g["input"]
+    assert sha(srv.many_sbox(x, inv=False)) == g["many_sbox"]
+    st, ek = c.encrypt_u128(c.iv), c.encrypt_u128(c.key)
+    rk = srv.aes_key_expansion(ek)
+    assert sha(rk) == g["round_keys"]
+    enc = srv.aes_encrypt(rk, st.copy())
+    assert sha(enc) == g["aes_encrypt"]
+    assert sha(srv.aes_decrypt(rk, enc.copy())) == g["aes_decrypt"]
+    assert sha(srv.add_scalar(st.copy(), 0x1FF)) == g["add_scalar_0x1ff"]
+    c.test_verify(enc, srv.aes_decryption(rk, enc.copy()))  # Client::test_verify (client.rs:178-216)
+
+
+@pytest.mark.parametrize("idx", range(5))
+def test_known_answer_vectors_on_gpu(toy, toy_server, golden, idx):
+    v = golden["aes_kat"][idx]
+    key, pt, want = int(v["key"], 16), int(v["plaintext"], 16), int(v["ciphertext"], 16)
+    c = toy.client
+    rk = toy_server.aes_key_expansion(c.encrypt_u128(key))
+    assert np.array_equal(c.decrypt_bytes(rk), np.array(aes_clear.expand_key(key), dtype=np.uint8))
+    enc = toy_server.aes_encrypt(rk, c.encrypt_u128(pt))
+    assert c.decrypt_u128(enc) == want
+    assert c.decrypt_u128(toy_server.aes_decrypt(rk, enc.copy())) == pt
+
+
+def test_batched_blocks_equal_per_block_oracle(toy, toy_server):
+    """CTR batch: 3 blocks in one call == the oracle block by block (blocks are independent, main.rs:55-64)"""
+    c, O = toy.client, toy.oracle
+    iv = 0xF0F1F2F3F4F5F6F7F8F9FAFBFCFDFEFF
+    rk = O.aes_key_expansion(c.encrypt_u128(c.key))
+    states = np.stack([c.encrypt_u128(iv)] * 3)
+    toy_server.add_scalar(states, [0, 1, 0x101])
+    for b, i in enumerate((0, 1, 0x101)):
+        assert c.decrypt_u128(states[b]) == iv + i
+    want = np.stack([O.aes_encrypt(rk, states[b]) for b in range(3)])
+    got = toy_server.aes_encrypt(rk, states.copy())
+    assert np.array_equal(got, want)
+    for b, i in enumerate((0, 1, 0x101)):
+        assert c.decrypt_u128(got[b]) == aes_clear.aes128_encrypt_block(c.key, iv + i)
+
+
+def test_device_resident_tensors_match_host_path(toy, toy_server):
+    import torch
+
+    c, p = toy.client, toy.params
+    st = c.encrypt_u128(0x00112233445566778899AABBCCDDEEFF)
+    rk = toy.oracle.aes_key_expansion(c.encrypt_u128(c.key))
+    host = toy_server.aes_encrypt(rk, st.copy())
+    d_rk = torch.from_numpy(rk.view(np.int64)).cuda()
+    d_st = torch.from_numpy(st.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    toy_server.aes_encrypt(d_rk, d_st)
+    toy_server.synchronize()
+    assert np.array_equal(d_st.cpu().numpy().view(np.uint64), host)
+    with pytest.raises(ValueError):
+        toy_server.aes_encrypt(rk, d_st)                   # mixed memory spaces are refused
+
+
+def test_many_sbox_param_opt(opt):
+    """one AES round's worth of S-Boxes (16 bytes = 128 bit-CBS) at the reference's parameter set"""
+    srv = Server(opt.keys, device=0, engine=opt.engine())
+    vals = list(range(0x50, 0x60))
+    x = opt.client.encrypt_bytes(vals)
+    got = srv.many_sbox(x, inv=False)
+    assert np.array_equal(got, opt.oracle.wopbs_batch(x, orc.build_lutset(orc.LUTSET_ENC_ROUND)))
+    dec = opt.client.decrypt_bytes(got)
+    for i, v in enumerate(vals):
+        s = aes_clear.SBOX[v]
+        assert list(dec[i]) == [s, aes_clear.mul2(s), aes_clear.mul3(s)]

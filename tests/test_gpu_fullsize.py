@@ -1,0 +1,55 @@
+"""BASELINE.json sizes on the MI355X, checked through size-independent properties (the oracle would need
+hours): every block decrypts to AES-CTR, decrypt(encrypt(x)) == x, and launches are deterministic."""
+import numpy as np
+import pytest
+
+from conftest import sha
+from tfhe_aes_amd import aes_clear
+from tfhe_aes_amd.server import Server
+
+pytestmark = pytest.mark.gpu
+
+IV = 0xF0F1F2F3F4F5F6F7F8F9FAFBFCFDFEFF
+
+
+@pytest.fixture(scope="module")
+def opt_server(opt):
+    return Server(opt.keys, device=0, engine=opt.engine())
+
+
+def test_128_ctr_blocks_param_opt(opt, opt_server):
+    """BASELINE configs[2]: 128 CTR blocks, full 10 rounds, on one MI355X"""
+    import torch
+
+    c, p = opt.client, opt.params
+    key = c.key
+    rk = opt_server.aes_key_expansion(c.encrypt_u128(key))
+    assert np.array_equal(c.decrypt_bytes(rk), np.array(aes_clear.expand_key(key), dtype=np.uint8))
+    n = 128
+    states = np.stack([c.encrypt_u128(IV + i) for i in range(n)])
+    d_rk = torch.from_numpy(rk.view(np.int64)).cuda()
+    d_st = torch.from_numpy(states.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    opt_server.aes_encrypt(d_rk, d_st)
+    opt_server.synchronize()
+    out = d_st.cpu().numpy().view(np.uint64)
+    for i in range(n):
+        assert c.decrypt_u128(out[i]) == aes_clear.aes128_encrypt_block(key, IV + i), "block %d" % i
+    # determinism at full size: a second launch on the same inputs gives the same words
+    d_st2 = torch.from_numpy(states.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    opt_server.aes_encrypt(d_rk, d_st2)
+    opt_server.synchronize()
+    assert sha(d_st2.cpu().numpy()) == sha(out)
+    # round trip on a few blocks (decrypt costs 1.9x, BASELINE configs[4] path)
+    back = opt_server.aes_decrypt(rk, out[:4].copy())
+    for i in range(4):
+        assert c.decrypt_u128(back[i]) == IV + i
+
+
+def test_ctr_counter_add_param_opt(opt, opt_server):
+    c = opt.client
+    st = np.stack([c.encrypt_u128(IV)] * 2)
+    opt_server.add_scalar(st, [0x1FF, 0xFFFFFFFF])
+    assert c.decrypt_u128(st[0]) == (IV + 0x1FF) % (1 << 128)
+    assert c.decrypt_u128(st[1]) == (IV + 0xFFFFFFFF) % (1 << 128)

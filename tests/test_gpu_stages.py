@@ -1,0 +1,114 @@
+"""Parity tests proper: every kernel of the hot path, called through the C ABI on the MI355X, against the CPU
+oracle on the same seeded inputs -- bit-exact (integer stages AND the f64 FFT stages, whose arithmetic is
+canonical: see oracle/fheaes_oracle.c header)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tfhe_aes_amd import _native
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(kit, m, seed):
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(0, 2, m).astype(np.uint8)
+    return kit.client.encrypt_bits(bits), bits
+
+
+@pytest.mark.parametrize("which", ["toy", "opt"])
+def test_twiddles_and_bsk_fourier(which, request):
+    kit = request.getfixturevalue(which)
+    p, E = kit.params, kit.engine()
+    assert np.array_equal(_native.get_twiddles().view(np.uint64), orc.twiddles().view(np.uint64))
+    bsk = kit.keys.bsk.reshape(p.n, p.pbs_level, p.k + 1, p.k + 1, 512)
+    for i in (0, p.n // 2, p.n - 1):
+        assert np.array_equal(E.read_bsk_fourier(i).view(np.uint64), orc.polys_to_fourier(bsk[i]).view(np.uint64))
+
+
+@pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 33), ("toy", 100), ("opt", 1), ("opt", 35)])
+def test_k1_keyswitch(which, m, request):
+    kit = request.getfixturevalue(which)
+    p, E = kit.params, kit.engine()
+    x, _ = _inputs(kit, m, 10 + m)
+    out = np.zeros((m, p.n + 1), dtype=np.uint64)
+    E.keyswitch_batch(x, out, m)
+    assert np.array_equal(out, kit.oracle.keyswitch(x))
+
+
+@pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 8), ("toy", 21), ("opt", 1), ("opt", 7)])
+def test_k2_blind_rotation(which, m, request):
+    kit = request.getfixturevalue(which)
+    p, E = kit.params, kit.engine()
+    x, bits = _inputs(kit, m, 20 + m)
+    small = kit.oracle.keyswitch(x)
+    out = np.zeros((m, p.big1), dtype=np.uint64)
+    E.cbs_pbs_batch(small, out, m)
+    assert np.array_equal(out, kit.oracle.cbs_pbs(small))
+    # and it means what it should: LWE of bit * 2^(64-15)
+    _, ph = kit.client.decrypt_bits(out, return_phase=True)
+    delta = 1 << (64 - p.cbs_base_log)
+    assert np.abs(ph.astype(np.int64) - bits.astype(np.int64) * delta).max() < delta // 8
+
+
+@pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 40), ("opt", 3), ("opt", 33)])
+def test_k3_pfpks(which, m, request):
+    kit = request.getfixturevalue(which)
+    p, E = kit.params, kit.engine()
+    rng = np.random.default_rng(30 + m)
+    x = rng.integers(0, 1 << 64, (m, p.big1), dtype=np.uint64)         # any LWE words: the kernel is pure integer
+    out = np.zeros((m, p.k + 1, (p.k + 1) * 512), dtype=np.uint64)
+    E.pfpks_batch(x, out, m)
+    assert np.array_equal(out, kit.oracle.pfpks(x))
+
+
+def test_k4_forward_fourier(toy):
+    E = toy.engine()
+    rng = np.random.default_rng(4)
+    for polys in (1, 15, 16, 17, 130):
+        x = rng.integers(0, 1 << 64, (polys, 512), dtype=np.uint64)
+        out = np.zeros((polys, 256, 2), dtype=np.float64)
+        E.forward_fourier_batch(x, out, polys)
+        assert np.array_equal(out.view(np.uint64), orc.polys_to_fourier(x).view(np.uint64))
+
+
+@pytest.mark.parametrize("which", ["toy", "opt"])
+def test_k5_vertical_packing(which, request):
+    kit = request.getfixturevalue(which)
+    p, E, c, O = kit.params, kit.engine(), kit.client, kit.oracle
+    vals = [0x53, 0xE1]
+    x = c.encrypt_bytes(vals)
+    luts = orc.build_lutset(orc.LUTSET_DEC_MUL)                        # 4 LUTs: 32 instances per byte, ragged vs R
+    want, dbg = O.wopbs_batch(x, luts, debug=True)
+    ggsw_f = orc.polys_to_fourier(dbg["ggsw"].reshape(2, 8, -1, 512))   # [inputs][bits][(k+1)^2][256][2]
+    out = np.zeros_like(want)
+    E.vertical_packing_batch(np.ascontiguousarray(ggsw_f), 2, 8, luts, 4, False, out)
+    assert np.array_equal(out, want)
+
+
+def test_zero_sized_batches_are_noops(toy):
+    p, E = toy.params, toy.engine()
+    x = np.zeros((1, p.big1), dtype=np.uint64)
+    out = np.full((1, p.n + 1), 7, dtype=np.uint64)
+    E.keyswitch_batch(x, out, 0)
+    assert (out == 7).all()
+
+
+def test_errors_are_status_codes(toy):
+    p = toy.params
+    E = _native.Engine(p)                                              # no keys uploaded
+    x = np.zeros((1, p.big1), dtype=np.uint64)
+    out = np.zeros((1, p.n + 1), dtype=np.uint64)
+    with pytest.raises(_native.FheAesError) as e:
+        E.keyswitch_batch(x, out, 1)
+    assert e.value.code == -2 and "keys" in str(e.value)
+    with pytest.raises(ValueError):
+        E.upload_keys(toy.keys.ksk[:-1].copy(), toy.keys.bsk, toy.keys.pfpksk)
+    E2 = toy.engine()
+    luts = orc.build_lutset(orc.LUTSET_SBOX)
+    for bits in (0, 10):
+        with pytest.raises(_native.FheAesError) as e:
+            E2.wopbs_batch(np.zeros((1, max(bits, 1), p.big1), dtype=np.uint64), 1, bits, luts, 1, False,
+                           np.zeros((1, 1, max(bits, 1), p.big1), dtype=np.uint64))
+        assert e.value.code == -1
+    E.close()

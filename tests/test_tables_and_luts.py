@@ -1,0 +1,95 @@
+"""AES tables, GF(2^8) helpers and LUT encoding (tables/table.rs, sbox.rs:20-42, gen_lut.rs:9-42)."""
+import numpy as np
+
+from oracle import oracle as orc
+from tfhe_aes_amd import _native, aes_clear
+from tfhe_aes_amd.server import gen_lut
+
+
+def test_tables_match_golden_and_fips197(golden):
+    assert bytes(aes_clear.SBOX).hex() == golden["sbox"]
+    assert bytes(aes_clear.INV_SBOX).hex() == golden["inv_sbox"]
+    # FIPS-197 figure 7 spot values
+    assert aes_clear.SBOX[0x00] == 0x63 and aes_clear.SBOX[0x53] == 0xED and aes_clear.SBOX[0xFF] == 0x16
+    assert all(aes_clear.INV_SBOX[aes_clear.SBOX[x]] == x for x in range(256))
+    s, i = orc.tables()
+    assert bytes(s).hex() == golden["sbox"] and bytes(i).hex() == golden["inv_sbox"]
+
+
+def test_gf_helpers_exhaustive():
+    # sbox.rs:20-42: mul2 reduces with 0x1B, the others are built from it
+    for x in range(256):
+        m2 = ((x << 1) ^ (0x1B if x & 0x80 else 0)) & 0xFF
+        assert aes_clear.mul2(x) == m2
+        assert aes_clear.mul3(x) == m2 ^ x
+        m4 = aes_clear.mul2(m2)
+        m8 = aes_clear.mul2(m4)
+        assert aes_clear.mul9(x) == m8 ^ x
+        assert aes_clear.mul11(x) == m8 ^ m2 ^ x
+        assert aes_clear.mul13(x) == m8 ^ m4 ^ x
+        assert aes_clear.mul14(x) == m8 ^ m4 ^ m2
+
+
+def test_aes_known_answers_in_the_clear(golden):
+    for v in golden["aes_kat"]:
+        k, pt, ct = int(v["key"], 16), int(v["plaintext"], 16), int(v["ciphertext"], 16)
+        assert aes_clear.aes128_encrypt_block(k, pt) == ct
+        assert aes_clear.aes128_decrypt_block(k, ct) == pt
+
+
+def _gen_lut_restated(nb_block, f):
+    """direct restatement of gen_lut.rs:9-42 for message_modulus 2, carry_modulus 1, polynomial_size 512"""
+    log_basis, delta = 1, 63
+    lut_size = max(1 << (nb_block * log_basis), 512)
+    lut = np.zeros((nb_block, lut_size), dtype=np.uint64)
+    for index in range(lut_size):
+        value, tmp = 0, index
+        for i in range(nb_block):
+            value += (tmp % 2) << i
+            tmp >>= 1
+        for b in range(nb_block):
+            lut[b, index] = ((f(value) >> b) % 2) << delta
+    return lut
+
+
+def test_gen_lut_matches_reference_semantics():
+    for nb, f in ((8, lambda x: aes_clear.SBOX[x]), (8, lambda x: (x + 77) % 256), (9, lambda x: ((x & 0xFF) + (x >> 8) + 200) % 256),
+                  (9, lambda x: 1 if (x & 0xFF) + (x >> 8) + 200 > 255 else 0), (1, lambda x: x ^ 1)):
+        want = _gen_lut_restated(nb, f)
+        table = [f(x) for x in range(1 << nb)]
+        assert np.array_equal(orc.gen_lut(nb, table), want)
+        assert np.array_equal(_native.gen_lut(nb, table), want)          # product (host side of the C ABI)
+        assert np.array_equal(gen_lut(2, 1, 512, nb, f), want)           # reference-shaped front end
+    # an 8-bit table is the 256-entry table twice
+    l8 = orc.gen_lut(8, list(aes_clear.SBOX))
+    assert np.array_equal(l8[:, :256], l8[:, 256:])
+
+
+def test_lut_sets_order():
+    """many_sbox returns [S, 2S, 3S] / [9x, 11x, 13x, 14x] in that order (sbox.rs:74-81)"""
+    enc = orc.build_lutset(orc.LUTSET_ENC_ROUND)
+    dec = orc.build_lutset(orc.LUTSET_DEC_MUL)
+    assert enc.shape == (3, 8, 512) and dec.shape == (4, 8, 512)
+
+    def table_of(lut):
+        return [int(sum(((int(lut[b, x]) >> 63) & 1) << b for b in range(8))) for x in range(256)]
+
+    S = aes_clear.SBOX
+    assert table_of(enc[0]) == list(S)
+    assert table_of(enc[1]) == [aes_clear.mul2(s) for s in S]
+    assert table_of(enc[2]) == [aes_clear.mul3(s) for s in S]
+    for lut, f in zip(dec, (aes_clear.mul9, aes_clear.mul11, aes_clear.mul13, aes_clear.mul14)):
+        assert table_of(lut) == [f(x) for x in range(256)]
+    assert table_of(orc.build_lutset(orc.LUTSET_INV_SBOX)[0]) == list(aes_clear.INV_SBOX)
+    assert table_of(orc.build_lutset(orc.LUTSET_IDENTITY)[0]) == list(range(256))
+
+
+def test_gen_lut_rejects_foreign_moduli():
+    import pytest
+
+    with pytest.raises(ValueError):
+        gen_lut(4, 1, 512, 8, lambda x: x)
+    with pytest.raises(ValueError):
+        gen_lut(2, 1, 1024, 8, lambda x: x)
+    with pytest.raises(ValueError):
+        _native.gen_lut(8, [0] * 17)

@@ -2,7 +2,7 @@
 
   tfhe_aes_amd/libfheaes.so         hipcc --offload-arch=gfx950   (HIP kernels + C ABI, the product)
   tfhe_aes_amd/libfheaes_client.so  gcc -fopenmp                   (host Client: keygen / encrypt / decrypt)
-  oracle/liboracle.so               make -C oracle                 (CPU checker, test infrastructure)
+(The CPU checker under oracle/ has its own Makefile; the product never builds or loads it.)
 """
 from __future__ import annotations
 
@@ -17,7 +17,6 @@ CSRC = PKG / "csrc"
 
 ENGINE_SO = PKG / "libfheaes.so"
 CLIENT_SO = PKG / "libfheaes_client.so"
-ORACLE_SO = ROOT / "oracle" / "liboracle.so"
 
 ENGINE_SOURCES = [CSRC / "engine.hip"]
 ENGINE_HEADERS = sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.hpp")) + [ROOT / "include" / "fheaes.h"]
@@ -68,12 +67,5 @@ def build_client(force: bool = False) -> Path:
     return CLIENT_SO
 
 
-def build_oracle(force: bool = False) -> Path:
-    src = ROOT / "oracle" / "fheaes_oracle.c"
-    if force or _stale(ORACLE_SO, [src]):
-        _run(["make", "-C", str(ROOT / "oracle"), "-B", "liboracle.so"])
-    return ORACLE_SO
-
-
 def build_all(force: bool = False):
-    return build_engine(force), build_client(force), build_oracle(force)
+    return build_engine(force), build_client(force)

@@ -71,6 +71,13 @@ def load_library(build: bool = True):
     if _lib is not None:
         return _lib
     path = _build.build_engine() if build else _build.ENGINE_SO
+    try:
+        # PyTorch-ROCm ships its own libamdhip64; two HIP runtimes in one process cannot both own the
+        # GPU ("No HIP GPUs are available" in whichever comes second).  Loading torch first makes
+        # libfheaes.so resolve its libamdhip64.so.7 dependency to the runtime torch already mapped.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not Path(path).exists():
         raise RuntimeError("libfheaes.so is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)")
     lib = ctypes.CDLL(str(path))
