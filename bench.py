@@ -39,12 +39,25 @@ def ext_product_flops(p) -> float:
     return (k1 * L + k1) * fft + k1 * L * k1 * 256 * 8.0
 
 
+def usable_cores() -> int:
+    """CPU share of this process: affinity mask, capped by the cgroup quota when there is one"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(p, keys, client, seconds_hint: float = 20.0):
     """time the oracle's many_sbox (one AES round of one block = 16 bytes = 128 bit-CBS) on all host cores"""
     from oracle import oracle as orc
 
     O = orc.Oracle(p, keys.ksk, keys.bsk, keys.pfpksk)
-    cores = orc.lib().orc_num_threads()
+    cores = usable_cores()
+    orc.lib().orc_set_threads(cores)
     luts = orc.build_lutset(orc.LUTSET_ENC_ROUND)
     x = client.encrypt_bytes(list(range(16)))
     n_done, t0 = 0, time.time()
