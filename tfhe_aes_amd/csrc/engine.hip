@@ -19,7 +19,6 @@
 #include "kern_linear.h"
 
 #define FHEAES_VERSION_STR "fheaes-mi355x 0.1 (gfx950)"
-#define KS_TM 32
 #define MAX_CHUNK_BITS 32768ull
 
 namespace {
@@ -179,7 +178,8 @@ struct fheaes_ctx {
     // shapes
     uint32_t n = 0, k = 0, k1 = 0, big = 0, big1 = 0;
     // keys
-    uint64_t *ksk = nullptr, *ksk_init = nullptr, *pfpksk = nullptr, *pfpksk_init = nullptr;
+    int8_t *ksk_frag = nullptr, *pfpksk_frag = nullptr;      // balanced key bytes in MFMA B-fragment order
+    uint32_t ks_ksteps = 0, ks_coltiles = 0, pf_ksteps = 0, pf_coltiles = 0;
     double2 *bskf = nullptr;
     bool have_keys = false;
     // tables
@@ -188,7 +188,7 @@ struct fheaes_ctx {
     uint64_t *lutset_d[LUTSET_COUNT] = {};
     int lutset_n[LUTSET_COUNT] = {};
     // workspace
-    DevBuf ws_small, ws_pbs, ws_ggsw, ws_ggswf, ws_vp, ws_tmp_a, ws_tmp_b, ws_luts, ws_misc;
+    DevBuf ws_small, ws_pbs, ws_ggsw, ws_ggswf, ws_vp, ws_tmp_a, ws_tmp_b, ws_luts, ws_misc, ws_digits;
     // profiling
     bool prof = false;
     struct Pending { hipEvent_t a, b; int stage; };
@@ -282,12 +282,17 @@ int launch_keyswitch(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *ou
 {
     if (m == 0) return FHEAES_OK;
     StageScope sc(c, FHEAES_STAGE_KEYSWITCH, m);
+    const uint64_t ct_tiles16 = ((m + KS_CT_TILE - 1) / KS_CT_TILE) * (KS_CT_TILE / 16);
+    TRY(ensure(c, c->ws_digits, ct_tiles16 * c->ks_ksteps * 1024));
+    int8_t *af = (int8_t *)c->ws_digits.p;
+    const uint64_t threads = ct_tiles16 * c->ks_ksteps * 64;
+    hipLaunchKernelGGL((digits_kernel<2, 6, 1>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, in, (uint64_t)c->big1, c->big, m, c->ks_ksteps, af);
     KeyswitchArgs a{};
-    a.in = in; a.in_stride = c->big1; a.n_in = c->big; a.body_index = (int32_t)c->big; a.body_col = c->n;
-    a.key = c->ksk; a.key_z_stride = 0; a.init = c->ksk_init; a.ncols = c->n + 1;
+    a.afrag = af; a.bfrag = c->ksk_frag; a.ksteps = c->ks_ksteps; a.coltiles = c->ks_coltiles;
+    a.in = in; a.in_stride = c->big1; a.body_index = (int32_t)c->big; a.body_col = c->n; a.ncols = c->n + 1;
     a.out = out; a.out_stride = c->n + 1; a.out_z_stride = 0; a.m = m;
-    dim3 grid((a.ncols + KS_THREADS - 1) / KS_THREADS, (unsigned)((m + KS_TM - 1) / KS_TM), 1);
-    hipLaunchKernelGGL((keyswitch_kernel<2, 6, KS_TM>), grid, dim3(KS_THREADS), 0, c->stream, a);
+    dim3 grid((c->ks_coltiles + 3) / 4, (unsigned)((m + KS_CT_TILE - 1) / KS_CT_TILE), 1);
+    hipLaunchKernelGGL((keyswitch_mfma_kernel<1>), grid, dim3(KS_THREADS), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return FHEAES_OK;
 }
@@ -297,13 +302,18 @@ int launch_pfpks(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *out, u
 {
     if (m == 0) return FHEAES_OK;
     StageScope sc(c, FHEAES_STAGE_PFPKS, m);
-    KeyswitchArgs a{};
     const uint32_t gsz = c->k1 * FHE_N;
-    a.in = in; a.in_stride = c->big1; a.n_in = c->big1; a.body_index = -1; a.body_col = 0;
-    a.key = c->pfpksk; a.key_z_stride = (uint64_t)c->big1 * c->p.pfks_level * gsz; a.init = c->pfpksk_init; a.ncols = gsz;
+    const uint64_t ct_tiles16 = ((m + KS_CT_TILE - 1) / KS_CT_TILE) * (KS_CT_TILE / 16);
+    TRY(ensure(c, c->ws_digits, ct_tiles16 * c->pf_ksteps * 2 * 1024));
+    int8_t *af = (int8_t *)c->ws_digits.p;
+    const uint64_t threads = ct_tiles16 * c->pf_ksteps * 64;
+    hipLaunchKernelGGL((digits_kernel<12, 3, 2>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, in, (uint64_t)c->big1, c->big1, m, c->pf_ksteps, af);
+    KeyswitchArgs a{};
+    a.afrag = af; a.bfrag = c->pfpksk_frag; a.ksteps = c->pf_ksteps; a.coltiles = c->pf_coltiles;
+    a.in = in; a.in_stride = c->big1; a.body_index = -1; a.body_col = 0; a.ncols = gsz;
     a.out = out; a.out_stride = out_stride; a.out_z_stride = gsz; a.m = m;
-    dim3 grid((gsz + KS_THREADS - 1) / KS_THREADS, (unsigned)((m + KS_TM - 1) / KS_TM), c->k1);
-    hipLaunchKernelGGL((keyswitch_kernel<12, 3, KS_TM>), grid, dim3(KS_THREADS), 0, c->stream, a);
+    dim3 grid((c->pf_coltiles + 3) / 4, (unsigned)((m + KS_CT_TILE - 1) / KS_CT_TILE), c->k1);
+    hipLaunchKernelGGL((keyswitch_mfma_kernel<2>), grid, dim3(KS_THREADS), 0, c->stream, a);
     HIP_TRY(c, hipGetLastError());
     return FHEAES_OK;
 }
@@ -547,7 +557,7 @@ void fheaes_destroy(fheaes_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &pe : c->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : c->free_events) (void)hipEventDestroy(ev);
-    void *ptrs[] = {c->ksk, c->ksk_init, c->pfpksk, c->pfpksk_init, c->bskf, c->psi_d, c->tw_d,
+    void *ptrs[] = {c->ksk_frag, c->pfpksk_frag, c->bskf, c->psi_d, c->tw_d, c->ws_digits.p,
                     c->ws_small.p, c->ws_pbs.p, c->ws_ggsw.p, c->ws_ggswf.p, c->ws_vp.p, c->ws_tmp_a.p, c->ws_tmp_b.p, c->ws_luts.p, c->ws_misc.p};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < LUTSET_COUNT; ++s) if (c->lutset_d[s]) (void)hipFree(c->lutset_d[s]);
@@ -599,33 +609,46 @@ int fheaes_upload_keys(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, 
     if (!c || !ksk || !bsk || !pfpksk) return c ? c->fail(FHEAES_ERR_INVALID, "null key pointer") : FHEAES_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t kw = fheaes_key_words(c, FHEAES_KEY_KSK), bw = fheaes_key_words(c, FHEAES_KEY_BSK), pw = fheaes_key_words(c, FHEAES_KEY_PFPKSK);
-    const hipMemcpyKind kind = memspace == FHEAES_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     c->have_keys = false;
-    if (!c->ksk) HIP_TRY(c, hipMalloc((void **)&c->ksk, kw * 8));
-    if (!c->pfpksk) HIP_TRY(c, hipMalloc((void **)&c->pfpksk, pw * 8));
+    // K1 / K3 keys: balanced int8 byte planes in MFMA fragment order (same byte count as the uint64 keys)
+    const uint32_t rows1 = c->big * c->p.ks_level, ncol1 = c->n + 1;
+    const uint32_t rows3 = c->big1 * c->p.pfks_level, ncol3 = c->k1 * FHE_N;
+    c->ks_ksteps = (rows1 + KS_KSTEP - 1) / KS_KSTEP; c->ks_coltiles = (ncol1 + 15) / 16;
+    c->pf_ksteps = (rows3 + KS_KSTEP - 1) / KS_KSTEP; c->pf_coltiles = (ncol3 + 15) / 16;
+    const size_t frag1 = (size_t)c->ks_ksteps * c->ks_coltiles * 8 * 1024;
+    const size_t frag3 = (size_t)c->k1 * c->pf_ksteps * c->pf_coltiles * 8 * 1024;
+    if (!c->ksk_frag) HIP_TRY(c, hipMalloc((void **)&c->ksk_frag, frag1));
+    if (!c->pfpksk_frag) HIP_TRY(c, hipMalloc((void **)&c->pfpksk_frag, frag3));
     if (!c->bskf) HIP_TRY(c, hipMalloc((void **)&c->bskf, bw * 8));
-    if (!c->ksk_init) HIP_TRY(c, hipMalloc((void **)&c->ksk_init, (size_t)(c->n + 1) * 8));
-    if (!c->pfpksk_init) HIP_TRY(c, hipMalloc((void **)&c->pfpksk_init, (size_t)c->k1 * c->k1 * FHE_N * 8));
-    HIP_TRY(c, hipMemcpyAsync(c->ksk, ksk, kw * 8, kind, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->pfpksk, pfpksk, pw * 8, kind, c->stream));
-    // BSK: standard domain -> Fourier (the reference holds it in Fourier form already, many_wopbs.rs:34-35)
-    const uint64_t *bsk_dev = bsk;
+    // stage the standard-domain words in HBM (largest key first), transform, free
     void *tmp = nullptr;
-    if (memspace != FHEAES_DEVICE) {
-        HIP_TRY(c, hipMalloc(&tmp, bw * 8));
-        HIP_TRY(c, hipMemcpyAsync(tmp, bsk, bw * 8, hipMemcpyHostToDevice, c->stream));
-        bsk_dev = (const uint64_t *)tmp;
+    const size_t tmp_words = std::max(std::max(kw, bw), pw);
+    if (memspace != FHEAES_DEVICE) HIP_TRY(c, hipMalloc(&tmp, tmp_words * 8));
+    auto staged = [&](const uint64_t *src, size_t words) -> const uint64_t * {
+        if (memspace == FHEAES_DEVICE) return src;
+        (void)hipMemcpyAsync(tmp, src, words * 8, hipMemcpyHostToDevice, c->stream);
+        return (const uint64_t *)tmp;
+    };
+    int rc = FHEAES_OK;
+    {
+        const uint64_t *d = staged(ksk, kw);
+        const uint64_t threads = (uint64_t)c->ks_ksteps * c->ks_coltiles * 64;
+        hipLaunchKernelGGL(keybytes_kernel, dim3((unsigned)((threads + 255) / 256), 1), dim3(256), 0, c->stream, d, (uint64_t)0, rows1, ncol1,
+                           c->ks_ksteps, c->ks_coltiles, c->ksk_frag);
+        if (memspace != FHEAES_DEVICE) (void)hipStreamSynchronize(c->stream);
     }
-    int rc = launch_forward_fourier(c, bsk_dev, bw / FHE_N, c->bskf, FHEAES_STAGE_GGSW_FFT);
-    c->stage_launches[FHEAES_STAGE_GGSW_FFT] = 0; c->stage_units[FHEAES_STAGE_GGSW_FFT] = 0;
-    if (rc == FHEAES_OK) {
-        // offset-digit corrections
-        const uint32_t ncol1 = c->n + 1, rows1 = c->big * c->p.ks_level;
-        hipLaunchKernelGGL(keysum_kernel, dim3((ncol1 + 255) / 256, 1), dim3(256), 0, c->stream, c->ksk, (uint64_t)0, rows1, ncol1,
-                           (uint64_t)(1ull << (c->p.ks_base_log - 1)), c->ksk_init);
-        const uint32_t ncol3 = c->k1 * FHE_N, rows3 = c->big1 * c->p.pfks_level;
-        hipLaunchKernelGGL(keysum_kernel, dim3((ncol3 + 255) / 256, c->k1), dim3(256), 0, c->stream, c->pfpksk, (uint64_t)rows3 * ncol3, rows3, ncol3,
-                           (uint64_t)(1ull << (c->p.pfks_base_log - 1)), c->pfpksk_init);
+    {
+        const uint64_t *d = staged(pfpksk, pw);
+        const uint64_t threads = (uint64_t)c->pf_ksteps * c->pf_coltiles * 64;
+        hipLaunchKernelGGL(keybytes_kernel, dim3((unsigned)((threads + 255) / 256), c->k1), dim3(256), 0, c->stream, d, (uint64_t)rows3 * ncol3, rows3, ncol3,
+                           c->pf_ksteps, c->pf_coltiles, c->pfpksk_frag);
+        if (memspace != FHEAES_DEVICE) (void)hipStreamSynchronize(c->stream);
+    }
+    {
+        // BSK: standard domain -> Fourier (the reference holds it in Fourier form already, many_wopbs.rs:34-35)
+        const uint64_t *d = staged(bsk, bw);
+        rc = launch_forward_fourier(c, d, bw / FHE_N, c->bskf, FHEAES_STAGE_GGSW_FFT);
+        c->stage_launches[FHEAES_STAGE_GGSW_FFT] = 0; c->stage_units[FHEAES_STAGE_GGSW_FFT] = 0;
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (tmp) (void)hipFree(tmp);

@@ -41,7 +41,10 @@ struct ExtProdArgs {
 };
 
 template <int K1, int LEVELS, int BASE_LOG, int R, bool VP>
-__global__ __launch_bounds__(EP_THREADS, 2) void extprod_rotate_kernel(const ExtProdArgs A)
+#ifndef EP_MIN_WAVES
+#define EP_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kernel(const ExtProdArgs A)
 {
     static_assert(R * K1 <= EP_GROUPS, "too many polynomials for 16 lane groups");
     __shared__ __attribute__((aligned(16))) double lds[EP_LDS_DOUBLES];
@@ -154,7 +157,9 @@ __global__ __launch_bounds__(EP_THREADS, 2) void extprod_rotate_kernel(const Ext
                     xi[a] = (double)decompose_next<BASE_LOG>(st_hi[a]);
                 }
             }
+#ifndef ABL_NO_FFT
             nega_fwd(xr, xi, psi, tw, tile, b, fc);
+#endif
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 double2 v; v.x = xr[k2]; v.y = xi[k2];
@@ -163,6 +168,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void extprod_rotate_kernel(const Ext
             __syncthreads();
             // ---- multiply-accumulate role: thread tid owns Fourier point tid ------------------
             const double2 *Gl = G + (size_t)l * K1 * K1 * FHE_H + tid;
+#ifndef ABL_NO_MAC
 #pragma unroll
             for (int p = 0; p < K1; ++p) {
                 double2 bv[K1];
@@ -180,6 +186,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void extprod_rotate_kernel(const Ext
                     }
                 }
             }
+#endif
             __syncthreads();
         }
 
@@ -198,7 +205,9 @@ __global__ __launch_bounds__(EP_THREADS, 2) void extprod_rotate_kernel(const Ext
             xr[k2] = v.x; xi[k2] = v.y;
         }
         wave_lds_sync();
+#ifndef ABL_NO_FFT
         nega_inv(xr, xi, psi, tw, tile, b, fc);
+#endif
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             lo[a] += torus_from_double(xr[a]);

@@ -1,115 +1,185 @@
-// kern_keyswitch.h -- the two integer key-switching kernels:
+// kern_keyswitch.h -- the two integer key-switching stages:
 //   K1  LWE keyswitch big -> small ("bit extraction")
 //   K3  private functional packing keyswitch LWE -> GLWE, k+1 keys (8 a13)
-// Both are  out[m][o] = init[o] (+ body) - sum_{i,l} digit_l(in[m][i]) * KEY[i][l][o]   in uint64 wrapping
-// arithmetic, i.e. a (ciphertexts x (inputs*levels)) by ((inputs*levels) x columns) product.
+// Both are  out[m][o] = (body) - sum_{i,l} digit_l(in[m][i]) * KEY[i][l][o]   in uint64 wrapping arithmetic.
+// Over a batch of M ciphertexts this is an exact integer matrix product
+//       D[M x Q] * KEY[Q x ncols]  (mod 2^64),   Q = inputs x levels  (6,147 x 12,800 per bit for K3),
+// and at the batch sizes of the path (M = 16,384 per AES round) it is arithmetic-bound, not HBM-bound:
+// the v_mad_u64_u32 form measured 8.9 T MAC/s (58 % of the half-rate integer-multiply issue limit).
+// The kernels below slice it exactly onto the i8 matrix cores instead:
+//   KEY = sum_j kb_j * 2^(8j)  with balanced bytes kb_j in [-128,127]   (precomputed at key upload)
+//   d   = dlo + 256*dhi        with dlo in [-128,127], dhi small        (digits_kernel, once per launch)
+//   d*KEY = sum_{j,k} 2^(8(j+k)) * (d_k * kb_j), j+k <= 7: 15 (K3) or 8 (K1) int8 products per u64 product,
+// each accumulated exactly in int32 by v_mfma_i32_16x16x64_i8 (|sum| <= Q*128*128 < 2^31) and recombined
+// with shifts in uint64.  Bit-exact against the oracle by construction (integer arithmetic, any order).
 //
-// Tiling: a 256-thread workgroup owns 256 key columns (one per thread: every key load is a
-// coalesced 2 KB row segment) and TM ciphertexts; digits are decomposed once per workgroup into
-// LDS and read back as wave-uniform broadcasts, so each 8-byte key element fetched feeds TM
-// multiply-adds.  Digits are stored with an offset (d' = d + B/2 >= 0) so the products are plain
-// unsigned v_mad_u64_u32; the offset is undone by init[o] = (B/2) * sum_{i,l} KEY[i][l][o],
-// which is computed once at key upload (keysum_kernel).
+// Operands are stored in HBM directly in MFMA fragment order, so every lane fetches its 16 operand bytes
+// with one coalesced 16-byte load (1 KB per wave per fragment) and nothing is staged through LDS:
+//   A (digits): [ct tile of 16][kstep][plane][lane 64][16 B]   lane l: ciphertext 16T + l%16, rows 64*kstep + 16*(l/16) + e
+//   B (key)   : [z][kstep][column tile of 16][byte plane j][lane 64][16 B]   lane l: column 16C + l%16, same rows
+// One wave owns a 64-ciphertext x 16-column output tile (4 x 8 int32x4 accumulators); the 4 waves of a
+// workgroup take 4 adjacent column tiles of the same 64 ciphertexts, so their A loads coincide in L1.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "fft_dev.h"
 
 #define KS_THREADS 256
-#define KS_KI 16          /* input elements decomposed per LDS chunk */
+#define KS_CT_TILE 64          /* ciphertexts per workgroup */
+#define KS_KSTEP 64            /* K rows per MFMA */
 
-struct KeyswitchArgs {
-    const uint64_t *in;        // [m][in_stride]
-    uint64_t in_stride;
-    uint32_t n_in;             // elements that are decomposed
-    int32_t body_index;        // >= 0: in[m][body_index] is added to column body_col (K1); < 0: none
-    uint32_t body_col;
-    const uint64_t *key;       // [z][n_in][LEVELS][ncols]
-    uint64_t key_z_stride;
-    const uint64_t *init;      // [z][ncols]
-    uint32_t ncols;
-    uint64_t *out;             // [m][out_stride], column o of key z at out[m*out_stride + z*out_z_stride + o]
-    uint64_t out_stride;
-    uint64_t out_z_stride;
-    uint64_t m;
-};
+typedef int ks_int4 __attribute__((ext_vector_type(4)));
 
-template <int BASE_LOG, int LEVELS, int TM>
-__global__ __launch_bounds__(KS_THREADS) void keyswitch_kernel(const KeyswitchArgs A)
+// ---- key bytes: u64 KEY[z][rows][ncols] -> balanced int8 planes in B-fragment order (run once at upload) ----
+__global__ __launch_bounds__(256) void keybytes_kernel(const uint64_t *key, uint64_t key_z_stride, uint32_t rows, uint32_t ncols,
+                                                       uint32_t ksteps, uint32_t coltiles, int8_t *frag)
 {
-    static_assert(TM % 8 == 0, "TM must be a multiple of 8");
-    __shared__ __attribute__((aligned(16))) uint16_t dig[KS_KI * LEVELS * TM];   // [i][l][m]
-    const int tid = threadIdx.x;
-    const uint32_t col = blockIdx.x * KS_THREADS + tid;
-    const bool col_ok = col < A.ncols;
-    const uint32_t colc = col_ok ? col : A.ncols - 1;
-    const uint64_t m0 = (uint64_t)blockIdx.y * TM;
-    const int z = blockIdx.z;
-    const uint64_t *key = A.key + (uint64_t)z * A.key_z_stride + colc;
-
-    uint64_t acc_lo[TM], acc_hi[TM];
+    // one thread per (kstep, coltile, lane); key index z = blockIdx.y
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = gid & 63;
+    const uint64_t t = gid >> 6;
+    const uint32_t C = t % coltiles;
+    const uint32_t ks = (uint32_t)(t / coltiles);
+    const uint32_t z = blockIdx.y;
+    if (ks >= ksteps) return;
+    const uint32_t col = C * 16 + (lane & 15);
+    const uint32_t row0 = ks * KS_KSTEP + (lane >> 4) * 16;
+    int8_t b[8][16];
 #pragma unroll
-    for (int m = 0; m < TM; ++m) { acc_lo[m] = 0; acc_hi[m] = 0; }
-
-    for (uint32_t i0 = 0; i0 < A.n_in; i0 += KS_KI) {
-        __syncthreads();
-        // cooperative decomposition of TM x KS_KI inputs
-        for (int e = tid; e < TM * KS_KI; e += KS_THREADS) {
-            int m = e / KS_KI, ii = e % KS_KI;
-            uint64_t mm = m0 + m;
-            uint32_t i = i0 + ii;
-            int d[LEVELS];
-            if (mm < A.m && i < A.n_in) decompose_all<BASE_LOG, LEVELS>(A.in[mm * A.in_stride + i], d);
-            else {
+    for (int e = 0; e < 16; ++e) {
+        uint64_t x = 0;
+        if (col < ncols && row0 + e < rows) x = key[(uint64_t)z * key_z_stride + (uint64_t)(row0 + e) * ncols + col];
+        uint32_t carry = 0;
 #pragma unroll
-                for (int l = 0; l < LEVELS; ++l) d[l] = -(1 << (BASE_LOG - 1));   // offset digit 0: contributes nothing
-            }
-#pragma unroll
-            for (int l = 0; l < LEVELS; ++l) dig[(ii * LEVELS + l) * TM + m] = (uint16_t)(d[l] + (1 << (BASE_LOG - 1)));
+        for (int j = 0; j < 8; ++j) {
+            uint32_t v = (uint32_t)((x >> (8 * j)) & 0xFF) + carry;      // 0..256
+            carry = v >= 128 ? 1u : 0u;
+            b[j][e] = (int8_t)(v & 0xFF);                                 // v - 256*carry as a signed byte
         }
-        __syncthreads();
-        const uint32_t ilim = (A.n_in - i0 < KS_KI) ? (A.n_in - i0) : KS_KI;
-        for (uint32_t ii = 0; ii < ilim; ++ii) {
+    }
+    int8_t *o = frag + ((((uint64_t)z * ksteps + ks) * coltiles + C) * 8) * 1024 + (uint64_t)lane * 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        ks_int4 w;
+        memcpy(&w, b[j], 16);
+        *reinterpret_cast<ks_int4 *>(o + (uint64_t)j * 1024) = w;
+    }
+}
+
+// ---- digits: LWE words -> int8 digit planes in A-fragment order ------------------------------------------
+template <int BASE_LOG, int LEVELS, int PLANES>
+__global__ __launch_bounds__(256) void digits_kernel(const uint64_t *in, uint64_t in_stride, uint32_t n_in, uint64_t m,
+                                                     uint32_t ksteps, int8_t *frag)
+{
+    // one thread per (ct tile T, kstep, lane): produces rows q0 .. q0+15 of ciphertext 16T + lane%16
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = gid & 63;
+    const uint64_t t = gid >> 6;
+    const uint32_t ks = t % ksteps;
+    const uint64_t T = t / ksteps;
+    const uint64_t ct = T * 16 + (lane & 15);
+    const uint32_t q0 = ks * KS_KSTEP + (lane >> 4) * 16;
+    int8_t lo[16], hi[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { lo[e] = 0; hi[e] = 0; }
+    if (ct < m) {
+        const uint32_t i0 = q0 / LEVELS;
+        constexpr int NI = (16 + LEVELS - 1) / LEVELS + 1;
+#pragma unroll
+        for (int ii = 0; ii < NI; ++ii) {
+            const uint32_t i = i0 + ii;
+            if (i >= n_in) break;
+            int d[LEVELS];
+            decompose_all<BASE_LOG, LEVELS>(in[ct * in_stride + i], d);
 #pragma unroll
             for (int l = 0; l < LEVELS; ++l) {
-                uint64_t kv = key[((uint64_t)(i0 + ii) * LEVELS + l) * A.ncols];
-                uint32_t klo = (uint32_t)kv, khi = (uint32_t)(kv >> 32);
-                const uint4 *dp = reinterpret_cast<const uint4 *>(dig + (ii * LEVELS + l) * TM);
+                const int e = (int)(i * LEVELS + l) - (int)q0;
+                if (e >= 0 && e < 16) {
+                    const int dl = ((d[l] + 128) & 255) - 128;
 #pragma unroll
-                for (int q = 0; q < TM / 8; ++q) {
-                    uint4 w = dp[q];
-                    uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        uint32_t d0 = ww[h] & 0xFFFFu, d1 = ww[h] >> 16;
-                        acc_lo[q * 8 + 2 * h] += (uint64_t)d0 * klo;
-                        acc_hi[q * 8 + 2 * h] += (uint64_t)d0 * khi;
-                        acc_lo[q * 8 + 2 * h + 1] += (uint64_t)d1 * klo;
-                        acc_hi[q * 8 + 2 * h + 1] += (uint64_t)d1 * khi;
-                    }
+                    for (int ee = 0; ee < 16; ++ee) if (ee == e) { lo[ee] = (int8_t)dl; hi[ee] = (int8_t)((d[l] - dl) >> 8); }
                 }
             }
         }
     }
-    if (!col_ok) return;
-    const uint64_t init = A.init[(uint64_t)z * A.ncols + col];
-#pragma unroll
-    for (int m = 0; m < TM; ++m) {
-        uint64_t mm = m0 + m;
-        if (mm >= A.m) break;
-        uint64_t v = init - (acc_lo[m] + (acc_hi[m] << 32));
-        if (A.body_index >= 0 && col == A.body_col) v += A.in[mm * A.in_stride + (uint32_t)A.body_index];
-        A.out[mm * A.out_stride + (uint64_t)z * A.out_z_stride + col] = v;
+    int8_t *o = frag + ((T * ksteps + ks) * PLANES) * 1024 + (uint64_t)lane * 16;
+    ks_int4 w;
+    memcpy(&w, lo, 16);
+    *reinterpret_cast<ks_int4 *>(o) = w;
+    if (PLANES == 2) {
+        memcpy(&w, hi, 16);
+        *reinterpret_cast<ks_int4 *>(o + 1024) = w;
     }
 }
 
-// init[z][o] = (B/2) * sum over rows of KEY[z][row][o]
-__global__ void keysum_kernel(const uint64_t *key, uint64_t key_z_stride, uint32_t rows, uint32_t ncols, uint64_t half_base, uint64_t *init)
+struct KeyswitchArgs {
+    const int8_t *afrag;       // [ct tiles][ksteps][PLANES][64][16]
+    const int8_t *bfrag;       // [z][ksteps][coltiles][8][64][16]
+    uint32_t ksteps, coltiles;
+    const uint64_t *in;        // original LWE words (for the body term of K1)
+    uint64_t in_stride;
+    int32_t body_index;        // >= 0: in[m][body_index] is added to column body_col; < 0: none
+    uint32_t body_col;
+    uint32_t ncols;
+    uint64_t *out;             // column o of key z at out[m*out_stride + z*out_z_stride + o]
+    uint64_t out_stride, out_z_stride;
+    uint64_t m;
+};
+
+template <int PLANES>
+__global__ __launch_bounds__(KS_THREADS, 2) void keyswitch_mfma_kernel(const KeyswitchArgs A)
 {
-    uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= ncols) return;
-    const uint64_t *k = key + (uint64_t)blockIdx.y * key_z_stride + col;
-    uint64_t s = 0;
-    for (uint32_t r = 0; r < rows; ++r) s += k[(uint64_t)r * ncols];
-    init[(uint64_t)blockIdx.y * ncols + col] = s * half_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t C = blockIdx.x * 4 + wave;                 // this wave's column tile
+    if (C >= A.coltiles) return;                              // whole wave exits together (no barriers in this kernel)
+    const uint64_t T0 = (uint64_t)blockIdx.y * (KS_CT_TILE / 16);
+    const uint32_t z = blockIdx.z;
+
+    ks_int4 acc[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[t][s] = (ks_int4){0, 0, 0, 0};
+
+    const int8_t *ap = A.afrag + (T0 * A.ksteps * PLANES) * 1024 + (uint64_t)lane * 16;
+    const int8_t *bp = A.bfrag + (((uint64_t)z * A.ksteps * A.coltiles + C) * 8) * 1024 + (uint64_t)lane * 16;
+    const uint64_t a_tile_stride = (uint64_t)A.ksteps * PLANES * 1024;      // between ciphertext tiles
+    const uint64_t b_step_stride = (uint64_t)A.coltiles * 8 * 1024;         // between k steps
+
+    for (uint32_t ks = 0; ks < A.ksteps; ++ks) {
+        ks_int4 a[4][PLANES], b[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const ks_int4 *>(bp + (uint64_t)ks * b_step_stride + (uint64_t)s * 1024);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl)
+                a[t][pl] = *reinterpret_cast<const ks_int4 *>(ap + (uint64_t)t * a_tile_stride + ((uint64_t)ks * PLANES + pl) * 1024);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][0], b[s], acc[t][s], 0, 0, 0);
+            if (PLANES == 2 && s >= 1) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][1], b[s - 1], acc[t][s], 0, 0, 0);
+            }
+        }
+    }
+
+    // D layout of v_mfma_*_16x16: lane l holds column l%16, rows 4*(l/16) + r, r = 0..3
+    const uint32_t col = C * 16 + (lane & 15);
+    if (col >= A.ncols) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint64_t ct = (T0 + t) * 16 + (uint64_t)(lane >> 4) * 4 + r;
+            if (ct >= A.m) continue;
+            uint64_t v = 0;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) v += (uint64_t)(int64_t)acc[t][s][r] << (8 * s);
+            v = (uint64_t)0 - v;
+            if (A.body_index >= 0 && col == A.body_col) v += A.in[ct * A.in_stride + (uint32_t)A.body_index];
+            A.out[ct * A.out_stride + (uint64_t)z * A.out_z_stride + col] = v;
+        }
 }

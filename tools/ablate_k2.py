@@ -1,0 +1,63 @@
+"""Developer tool: time the blind-rotation kernel (K2) for builds with phases compiled out.
+Builds variants of libfheaes.so into gpurun_out/abl/ and times fheaes_cbs_pbs_batch on M resident bits.
+usage: python tools/ablate_k2.py [M]"""
+import ctypes
+import subprocess
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import torch  # noqa: E402,F401  (HIP runtime first, see _native.load_library)
+
+from tfhe_aes_amd import PARAM_OPT, _build, _native  # noqa: E402
+from tfhe_aes_amd.client import Client  # noqa: E402
+
+VARIANTS = {
+    "base": [],
+    "waves1": ["-DEP_MIN_WAVES=1"],
+    "no_mac": ["-DABL_NO_MAC"],
+    "no_fft": ["-DABL_NO_FFT"],
+    "no_mac_no_fft": ["-DABL_NO_MAC", "-DABL_NO_FFT"],
+}
+
+
+def main():
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+    names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(VARIANTS)
+    out = Path("gpurun_out/abl")
+    out.mkdir(parents=True, exist_ok=True)
+    p = PARAM_OPT
+    c = Client(1, 1, 2, params=p)
+    keys = c.server_keys()
+    rng = np.random.default_rng(0)
+    small = rng.integers(0, 1 << 64, (M, p.n + 1), dtype=np.uint64)
+    for name in names:
+        so = out / ("libfheaes_%s.so" % name)
+        cmd = [_build.hipcc_path()] + _build.engine_flags() + VARIANTS[name] + ["-o", str(so), str(_build.ENGINE_SOURCES[0])]
+        subprocess.run(cmd, check=True, capture_output=True)
+        lib = ctypes.CDLL(str(so))
+        for fn, (res, args) in _native.SIGNATURES.items():
+            f = getattr(lib, fn)
+            f.restype, f.argtypes = res, args
+        h = ctypes.c_void_p()
+        cp = p.c_struct()
+        assert lib.fheaes_create(ctypes.byref(cp), 0, ctypes.byref(h)) == 0
+        assert lib.fheaes_upload_keys(h, keys.ksk.ctypes.data, keys.bsk.ctypes.data, keys.pfpksk.ctypes.data, 0) == 0
+        d_in = torch.from_numpy(small.view(np.int64)).cuda()
+        d_out = torch.empty((M, p.big1), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter()
+            assert lib.fheaes_cbs_pbs_batch(h, d_in.data_ptr(), M, 1, d_out.data_ptr(), 1) == 0
+            lib.fheaes_synchronize(h)
+            ts.append(time.perf_counter() - t)
+        print("%-16s M=%d  %.1f ms  (runs: %s)" % (name, M, 1e3 * min(ts), " ".join("%.1f" % (1e3 * x) for x in ts)), flush=True)
+        lib.fheaes_destroy(h)
+
+
+if __name__ == "__main__":
+    main()
