@@ -15,6 +15,14 @@
 #include "fft_dev.h"
 
 #define EP_THREADS 256
+#ifdef ABL_MAC_NOLOAD   /* developer ablation: no key traffic */
+#define EP_LOADB(expr, p, c) make_double2((double)(tid + (c) + (p)), (double)(tid - (c)))
+#else
+#define EP_LOADB(expr, p, c) (expr)
+#endif
+#ifndef EP_PREFETCH
+#define EP_PREFETCH 2
+#endif
 #define EP_GROUPS 16
 #define EP_LDS_DOUBLES (EP_GROUPS * GROUP_TILE_DOUBLES + 2 * 2 * FHE_H)
 
@@ -148,15 +156,10 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
 #pragma unroll
             for (int c = 0; c < K1; ++c) { fr[r][c] = 0.0; fi[r][c] = 0.0; }
 
-#pragma unroll 1
-        for (int l = LEVELS - 1; l >= 0; --l) {
-            if (l != LEVELS - 1) {
-#pragma unroll
-                for (int a = 0; a < 16; ++a) {
-                    xr[a] = (double)decompose_next<BASE_LOG>(st_lo[a]);
-                    xi[a] = (double)decompose_next<BASE_LOG>(st_hi[a]);
-                }
-            }
+        // One decomposition level: transform the digit polynomials, exchange through LDS, multiply-accumulate.
+        // (A lambda called once for the first level and once inside the loop, so that xr/xi are provably dead
+        // during the multiply-accumulate of every level: no loop-carried copy survives the level.)
+        auto level_body = [&](const int l) {
 #ifndef ABL_NO_FFT
             nega_fwd(xr, xi, psi, tw, tile, b, fc);
 #endif
@@ -169,14 +172,34 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
             // ---- multiply-accumulate role: thread tid owns Fourier point tid ------------------
             const double2 *Gl = G + (size_t)l * K1 * K1 * FHE_H + tid;
 #ifndef ABL_NO_MAC
+            // The K1 x K1 GGSW entries of this level stream from L2; without software pipelining every
+            // row costs one exposed round trip (measured: 71 of 341 ms).  xr/xi are dead here, so PF rows
+            // are kept in flight in their registers.
+            constexpr int PF = (K1 < EP_PREFETCH) ? K1 : EP_PREFETCH;
+            double2 bq[PF][K1];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < PF; ++p)
+#pragma unroll
+                for (int c = 0; c < K1; ++c) bq[p][c] = EP_LOADB(Gl[(size_t)(p * K1 + c) * FHE_H], p, c);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int p = 0; p < K1; ++p) {
                 double2 bv[K1];
 #pragma unroll
-                for (int c = 0; c < K1; ++c) bv[c] = Gl[(size_t)(p * K1 + c) * FHE_H];
+                for (int c = 0; c < K1; ++c) bv[c] = bq[p % PF][c];
+                if (p + PF < K1) {
+#pragma unroll
+                    for (int c = 0; c < K1; ++c) bq[p % PF][c] = EP_LOADB(Gl[(size_t)((p + PF) * K1 + c) * FHE_H], p, c);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
+#ifdef ABL_MAC_NOLDS
+                    double2 d; d.x = (double)(tid + r); d.y = (double)(p - tid);
+#else
                     double2 d = *reinterpret_cast<const double2 *>(lds + (r * K1 + p) * GROUP_TILE_DOUBLES + 2 * tid);
+#endif
 #pragma unroll
                     for (int c = 0; c < K1; ++c) {
                         fr[r][c] = __builtin_fma(d.x, bv[c].x, fr[r][c]);
@@ -185,9 +208,20 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
                         fi[r][c] = __builtin_fma(d.y, bv[c].x, fi[r][c]);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
 #endif
             __syncthreads();
+        };
+        level_body(LEVELS - 1);
+#pragma unroll 1
+        for (int l = LEVELS - 2; l >= 0; --l) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                xr[a] = (double)decompose_next<BASE_LOG>(st_lo[a]);
+                xi[a] = (double)decompose_next<BASE_LOG>(st_hi[a]);
+            }
+            level_body(l);
         }
 
         // ---- products back to the owning groups, inverse transform, accumulate ----------------

@@ -17,6 +17,11 @@ from tfhe_aes_amd.client import Client  # noqa: E402
 
 VARIANTS = {
     "base": [],
+    "pf1": ["-DEP_PREFETCH=1"],
+    "pf2": ["-DEP_PREFETCH=2"],
+    "pf3": ["-DEP_PREFETCH=3"],
+    "mac_noload": ["-DABL_MAC_NOLOAD"],
+    "mac_nolds": ["-DABL_MAC_NOLDS"],
     "waves1": ["-DEP_MIN_WAVES=1"],
     "no_mac": ["-DABL_NO_MAC"],
     "no_fft": ["-DABL_NO_FFT"],
