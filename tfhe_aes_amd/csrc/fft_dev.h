@@ -110,8 +110,10 @@ __device__ __forceinline__ void group_transpose(double (&xr)[16], double (&xi)[1
 // Forward negacyclic transform.  In: xr[a] = p[16a+b], xi[a] = p[256+16a+b] (already doubles).
 // Out: lane k1 (= b) holds X[k1 + 16*k2] in (xr[k2], xi[k2]).
 // psi: LDS table psi[j] (j < 256) as double2; tw: LDS table tw[k1*16+b] = w256^(k1*b).
-__device__ __forceinline__ void nega_fwd(double (&xr)[16], double (&xi)[16], const double2 *psi, const double2 *tw,
-                                         double *tile, int b, const FftConsts fc)
+// Split in two halves: the head touches only registers and the read-only tables, the tail is the
+// first to write the group's tile (a caller may put a workgroup barrier between them).
+__device__ __forceinline__ void nega_fwd_head(double (&xr)[16], double (&xi)[16], const double2 *psi, const double2 *tw,
+                                              int b, const FftConsts fc)
 {
 #pragma unroll
     for (int a = 0; a < 16; ++a) {
@@ -124,8 +126,19 @@ __device__ __forceinline__ void nega_fwd(double (&xr)[16], double (&xi)[16], con
         double2 w = tw[16 * k1 + b];
         cmul(xr[k1], xi[k1], w.x, w.y);
     }
+}
+
+__device__ __forceinline__ void nega_fwd_tail(double (&xr)[16], double (&xi)[16], double *tile, int b, const FftConsts fc)
+{
     group_transpose(xr, xi, tile, b);
     dft16<false>(xr, xi, fc);
+}
+
+__device__ __forceinline__ void nega_fwd(double (&xr)[16], double (&xi)[16], const double2 *psi, const double2 *tw,
+                                         double *tile, int b, const FftConsts fc)
+{
+    nega_fwd_head(xr, xi, psi, tw, b, fc);
+    nega_fwd_tail(xr, xi, tile, b, fc);
 }
 
 // Inverse (unscaled, untwisted by conj psi).  In: lane k1 holds F[k1 + 16*k2] in index k2.
@@ -155,7 +168,7 @@ __device__ __forceinline__ uint64_t torus_from_double(double v)
     w -= __builtin_rint(w);
     double r = __builtin_rint(w * 0x1p64);
     if (r >= 0x1p63) r -= 0x1p64;
-    return (uint64_t)(long long)r;
+    return (uint64_t)(long long)r;      // (a hand-split floor/fma conversion measured 5 % slower than the compiler's)
 }
 
 __device__ __forceinline__ double double_from_torus(uint64_t x) { return (double)(long long)x; }

@@ -159,9 +159,20 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
         // One decomposition level: transform the digit polynomials, exchange through LDS, multiply-accumulate.
         // (A lambda called once for the first level and once inside the loop, so that xr/xi are provably dead
         // during the multiply-accumulate of every level: no loop-carried copy survives the level.)
-        auto level_body = [&](const int l) {
+        auto level_body = [&](const int l, const bool tiles_busy) {
+#ifndef EP_LATE_BARRIER
+            if (tiles_busy) __syncthreads();
+#endif
+            // first half of the transform needs no tile; the barrier that frees the tiles (other threads
+            // may still be reading the previous level's digits) sits as late as possible
 #ifndef ABL_NO_FFT
-            nega_fwd(xr, xi, psi, tw, tile, b, fc);
+            nega_fwd_head(xr, xi, psi, tw, b, fc);
+#endif
+#ifdef EP_LATE_BARRIER
+            if (tiles_busy) __syncthreads();
+#endif
+#ifndef ABL_NO_FFT
+            nega_fwd_tail(xr, xi, tile, b, fc);
 #endif
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
@@ -211,9 +222,8 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
-            __syncthreads();
         };
-        level_body(LEVELS - 1);
+        level_body(LEVELS - 1, false);
 #pragma unroll 1
         for (int l = LEVELS - 2; l >= 0; --l) {
 #pragma unroll
@@ -221,10 +231,11 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
                 xr[a] = (double)decompose_next<BASE_LOG>(st_lo[a]);
                 xi[a] = (double)decompose_next<BASE_LOG>(st_hi[a]);
             }
-            level_body(l);
+            level_body(l, true);
         }
 
         // ---- products back to the owning groups, inverse transform, accumulate ----------------
+        __syncthreads();             // every thread is done reading the last level's digits from the tiles
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll

@@ -17,6 +17,8 @@ from tfhe_aes_amd.client import Client  # noqa: E402
 
 VARIANTS = {
     "base": [],
+    "late_barrier": ["-DEP_LATE_BARRIER"],
+    "old_conv": ["-DEP_OLD_CONV"],
     "pf1": ["-DEP_PREFETCH=1"],
     "pf2": ["-DEP_PREFETCH=2"],
     "pf3": ["-DEP_PREFETCH=3"],
