@@ -339,7 +339,10 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
     const uint64_t half_delta = 1ull << (64 - c->p.cbs_base_log * level - 1);
     a.tv_const = (uint64_t)0 - half_delta; a.body_shift = 1ull << 62; a.post_add = half_delta;
     if (c->k1 == 5) {
-        constexpr int R = 3;
+#ifndef PBS_R
+#define PBS_R 3
+#endif
+        constexpr int R = PBS_R;
         hipLaunchKernelGGL((extprod_rotate_kernel<5, 5, 8, R, false>), dim3((unsigned)((m + R - 1) / R)), dim3(EP_THREADS), 0, c->stream, a);
     } else {
         constexpr int R = 8;

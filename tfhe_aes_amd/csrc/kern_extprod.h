@@ -15,6 +15,9 @@
 #include "fft_dev.h"
 
 #define EP_THREADS 256
+#ifndef EP_ROT_CHUNK
+#define EP_ROT_CHUNK 4
+#endif
 #ifdef ABL_MAC_NOLOAD   /* developer ablation: no key traffic */
 #define EP_LOADB(expr, p, c) make_double2((double)(tid + (c) + (p)), (double)(tid - (c)))
 #else
@@ -147,6 +150,8 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
             v0 -= lo[a]; v1 -= hi[a];
             xr[a] = (double)decompose_first<BASE_LOG, LEVELS>(v0, st_lo[a]);
             xi[a] = (double)decompose_first<BASE_LOG, LEVELS>(v1, st_hi[a]);
+            // bound the number of rotated coefficients in flight (each is 2 VGPRs on top of acc, state and digits)
+            if ((a & (EP_ROT_CHUNK - 1)) == EP_ROT_CHUNK - 1) __builtin_amdgcn_sched_barrier(0);
         }
         wave_lds_sync();
 

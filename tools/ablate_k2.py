@@ -17,6 +17,9 @@ from tfhe_aes_amd.client import Client  # noqa: E402
 
 VARIANTS = {
     "base": [],
+    "r2": ["-DPBS_R=2"],
+    "r2_pf3": ["-DPBS_R=2", "-DEP_PREFETCH=3"],
+    "r1": ["-DPBS_R=1"],
     "late_barrier": ["-DEP_LATE_BARRIER"],
     "old_conv": ["-DEP_OLD_CONV"],
     "pf1": ["-DEP_PREFETCH=1"],
