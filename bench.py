@@ -85,13 +85,14 @@ def main():
     ap.add_argument("--params", default="opt", choices=["opt", "toy"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--decrypt", action="store_true", help="time Server::aes_decrypt (BASELINE configs[4] path) instead of aes_encrypt")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
     from tfhe_aes_amd import PARAM_OPT, PARAM_TOY, _native
-    from tfhe_aes_amd.aes_clear import aes128_encrypt_block
+    from tfhe_aes_amd.aes_clear import aes128_decrypt_block, aes128_encrypt_block
     from tfhe_aes_amd.client import Client
     from tfhe_aes_amd.dist import broadcast_keys, broadcast_tensor, shard_blocks
 
@@ -153,15 +154,16 @@ def main():
         torch.cuda.synchronize()
         eng.synchronize()
 
+    step = eng.aes_decrypt if args.decrypt else eng.aes_encrypt
     for _ in range(args.warmup):
-        eng.aes_encrypt(rk, state, n_blocks)
+        step(rk, state, n_blocks)
     eng.synchronize()
     eng.profile_enable(True)
     eng.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.aes_encrypt(rk, state, n_blocks)
+        step(rk, state, n_blocks)
     eng.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -180,7 +182,7 @@ def main():
             got = client.decrypt_u128(state[idx].cpu().numpy().view(np.uint64))
             want = counters[idx]
             for _ in range(args.warmup + args.steps):
-                want = aes128_encrypt_block(KEY, want)
+                want = aes128_decrypt_block(KEY, want) if args.decrypt else aes128_encrypt_block(KEY, want)
             if got != want:
                 verified = False
         if world > 1:
@@ -218,12 +220,13 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64+f64", "data": "synthetic",
             "config": {
-                "workload": "configs[2]: %d CTR blocks per GPU, Server::aes_encrypt 10 rounds (1280 bit-CBS/block), "
-                            "counters pre-incremented client-side" % args.blocks,
+                "workload": ("configs[4] path: %d blocks per GPU, Server::aes_decrypt (2432 bit-CBS/block)" % args.blocks) if args.decrypt else
+                            ("configs[2]: %d CTR blocks per GPU, Server::aes_encrypt 10 rounds (1280 bit-CBS/block), "
+                             "counters pre-incremented client-side" % args.blocks),
                 "params": p.name, "blocks_per_gpu": args.blocks, "total_blocks": total_blocks,
-                "bit_cbs_per_step_per_gpu": args.blocks * 1280,
+                "bit_cbs_per_step_per_gpu": args.blocks * (2432 if args.decrypt else 1280),
             },
-            "ms_per_sbox": ms_per_step / (args.blocks * 160.0),
+            "ms_per_sbox": ms_per_step / (args.blocks * (304.0 if args.decrypt else 160.0)),
             "verified_vs_aes": verified,
             "stage_ms_per_step": stage_ms,
             "roofline": {

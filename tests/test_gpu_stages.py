@@ -112,3 +112,22 @@ def test_errors_are_status_codes(toy):
                            np.zeros((1, 1, max(bits, 1), p.big1), dtype=np.uint64))
         assert e.value.code == -1
     E.close()
+
+
+def test_large_batches_are_chunked_consistently(toy):
+    """more bits than one workspace chunk (32,768): the chunked call equals the same inputs processed in two calls"""
+    p, E, c = toy.params, toy.engine(), toy.client
+    n = 4200                                                           # 33,600 bits > MAX_CHUNK_BITS
+    rng = np.random.default_rng(5)
+    x = c.encrypt_bytes(rng.integers(0, 256, n))
+    luts = orc.build_lutset(orc.LUTSET_SBOX)
+    whole = np.zeros((n, 1, 8, p.big1), dtype=np.uint64)
+    E.wopbs_batch(x, n, 8, luts, 1, False, whole)
+    half = n // 2
+    parts = np.zeros_like(whole)
+    E.wopbs_batch(x[:half], half, 8, luts, 1, False, parts[:half])
+    E.wopbs_batch(np.ascontiguousarray(x[half:]), n - half, 8, luts, 1, False, parts[half:])
+    assert np.array_equal(whole, parts)
+    # spot-check against the oracle and the S-Box
+    idx = [0, half - 1, half, n - 1]
+    assert np.array_equal(whole[idx], toy.oracle.wopbs_batch(x[idx], luts))
