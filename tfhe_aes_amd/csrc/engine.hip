@@ -312,8 +312,16 @@ int launch_pfpks(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *out, u
     a.afrag = af; a.bfrag = c->pfpksk_frag; a.ksteps = c->pf_ksteps; a.coltiles = c->pf_coltiles;
     a.in = in; a.in_stride = c->big1; a.body_index = -1; a.body_col = 0; a.ncols = gsz;
     a.out = out; a.out_stride = out_stride; a.out_z_stride = gsz; a.m = m;
+#ifndef KS_LDS
+#define KS_LDS 1
+#endif
+#if KS_LDS
+    dim3 grid((c->pf_coltiles + KSL_COL_TILES - 1) / KSL_COL_TILES, (unsigned)((m + 16 * KSL_CT_TILES - 1) / (16 * KSL_CT_TILES)), c->k1);
+    hipLaunchKernelGGL((keyswitch_mfma_lds_kernel<2>), grid, dim3(KSL_THREADS), 0, c->stream, a);
+#else
     dim3 grid((c->pf_coltiles + 3) / 4, (unsigned)((m + KS_CT_TILE - 1) / KS_CT_TILE), c->k1);
     hipLaunchKernelGGL((keyswitch_mfma_kernel<2>), grid, dim3(KS_THREADS), 0, c->stream, a);
+#endif
     HIP_TRY(c, hipGetLastError());
     return FHEAES_OK;
 }

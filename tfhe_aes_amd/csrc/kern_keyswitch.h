@@ -183,3 +183,100 @@ __global__ __launch_bounds__(KS_THREADS, 2) void keyswitch_mfma_kernel(const Key
             A.out[ct * A.out_stride + (uint64_t)z * A.out_z_stride + col] = v;
         }
 }
+
+
+// ---- LDS-tiled form: 512 threads = 8 waves own a 128-ciphertext x 64-column output tile -------------------
+// The one-wave-one-tile kernel above is bound by the L2 -> CU operand stream (40 KB per 240 MFMAs: measured
+// 36 % of the int8 MFMA rate).  Here the 8 digit fragments and the 32 key fragments of a K step are brought in
+// ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPR staging; the
+// fragments are already stored in MFMA lane order, so the LDS image is the HBM image) and read by every wave
+// that needs them: 48 KB per 480 MFMAs.  Double buffered: the loads of step ks+1 fly during the MFMAs of ks.
+#define KSL_THREADS 512
+#define KSL_CT_TILES 8          /* 128 ciphertexts */
+#define KSL_COL_TILES 4         /* 64 columns */
+
+template <int PLANES>
+__global__ __launch_bounds__(KSL_THREADS, 2) void keyswitch_mfma_lds_kernel(const KeyswitchArgs A)
+{
+    constexpr int A_FRAGS = KSL_CT_TILES * PLANES;
+    constexpr int B_FRAGS = KSL_COL_TILES * 8;
+    constexpr int FRAGS = A_FRAGS + B_FRAGS;                  // 1 KB each
+    __shared__ __attribute__((aligned(16))) int8_t lds[2 * FRAGS * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wc = wave & 3, wt = wave >> 2;                  // column tile / ciphertext half of this wave
+    const uint32_t C0 = blockIdx.x * KSL_COL_TILES;
+    const uint64_t T0 = (uint64_t)blockIdx.y * KSL_CT_TILES;
+    const uint32_t z = blockIdx.z;
+    const uint64_t ct_tiles_total = (A.m + 15) / 16;
+
+    ks_int4 acc[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[t][s] = (ks_int4){0, 0, 0, 0};
+
+    // fragment f of a K step: f < A_FRAGS: digits (ct tile f / PLANES, plane f % PLANES); else key (col tile, byte plane)
+    auto issue = [&](uint32_t ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < (FRAGS + 7) / 8; ++i) {
+            const int f = wave + 8 * i;                        // wave-uniform
+            if (f < FRAGS) {
+                const int8_t *src;
+                if (f < A_FRAGS) {
+                    uint64_t T = T0 + f / PLANES;
+                    if (T >= ct_tiles_total) T = ct_tiles_total - 1;          // clamp: rows beyond m are never stored
+                    src = A.afrag + ((T * A.ksteps + ks) * PLANES + (f % PLANES)) * 1024;
+                } else {
+                    const int g = f - A_FRAGS;
+                    uint32_t C = C0 + g / 8;
+                    if (C >= A.coltiles) C = A.coltiles - 1;
+                    src = A.bfrag + ((((uint64_t)z * A.ksteps + ks) * A.coltiles + C) * 8 + (g % 8)) * 1024;
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + lane * 16),
+                                                 (__attribute__((address_space(3))) void *)(lds + ((size_t)buf * FRAGS + f) * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    issue(0, 0);
+    for (uint32_t ks = 0; ks < A.ksteps; ++ks) {
+        const int buf = ks & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's fragments of step ks have landed
+        __syncthreads();                                      // everybody's have, and step ks-1 is fully consumed
+        if (ks + 1 < A.ksteps) issue(ks + 1, buf ^ 1);
+        const int8_t *base = lds + (size_t)buf * FRAGS * 1024 + lane * 16;
+        ks_int4 a[4][PLANES], b[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const ks_int4 *>(base + (A_FRAGS + wc * 8 + s) * 1024);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) a[t][pl] = *reinterpret_cast<const ks_int4 *>(base + ((wt * 4 + t) * PLANES + pl) * 1024);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][0], b[s], acc[t][s], 0, 0, 0);
+            if (PLANES == 2 && s >= 1) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][1], b[s - 1], acc[t][s], 0, 0, 0);
+            }
+        }
+    }
+
+    const uint32_t C = C0 + wc;
+    const uint32_t col = C * 16 + (lane & 15);
+    if (C >= A.coltiles || col >= A.ncols) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint64_t ct = (T0 + wt * 4 + t) * 16 + (uint64_t)(lane >> 4) * 4 + r;
+            if (ct >= A.m) continue;
+            uint64_t v = 0;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) v += (uint64_t)(int64_t)acc[t][s][r] << (8 * s);
+            v = (uint64_t)0 - v;
+            if (A.body_index >= 0 && col == A.body_col) v += A.in[ct * A.in_stride + (uint32_t)A.body_index];
+            A.out[ct * A.out_stride + (uint64_t)z * A.out_z_stride + col] = v;
+        }
+}
