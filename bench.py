@@ -190,6 +190,20 @@ def main():
             dist.all_reduce(v, op=dist.ReduceOp.MIN)
             verified = bool(v.item())
 
+    # ---- BASELINE configs[1]: one AES block = 16 S-Box WoPBS in one call (latency, not throughput) ------------
+    one_block_ms = None
+    if rank == 0:
+        xb = state[0].clone()
+        ob = torch.empty((16, 3, 8, p.big1), dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        eng.many_sbox(xb, 16, False, ob)
+        eng.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.many_sbox(xb, 16, False, ob)
+        eng.synchronize()
+        one_block_ms = 1000.0 * (time.perf_counter() - t0) / 3
+
     if rank == 0:
         total_blocks = args.blocks * world
         value = total_blocks * args.steps / elapsed
@@ -228,6 +242,8 @@ def main():
             },
             "ms_per_sbox": ms_per_step / (args.blocks * (304.0 if args.decrypt else 160.0)),
             "verified_vs_aes": verified,
+            "config1_one_block_round": {"many_sbox_16_bytes_ms": one_block_ms, "ms_per_sbox": None if one_block_ms is None else one_block_ms / 16.0,
+                                        "note": "BASELINE configs[1]: 16 S-Box WoPBS (128 bit-CBS) in one call: latency of the 669-step rotation chain"},
             "stage_ms_per_step": stage_ms,
             "roofline": {
                 "kernel": "extprod_rotate_kernel (blind rotation, K2)", "bound": "hbm",

@@ -24,7 +24,7 @@ def test_library_is_built_in_tree_for_gfx950():
     assert so.exists() and so.parent == _build.PKG
     blob = so.read_bytes()
     assert b"gfx950" in blob                                # embedded code object target
-    assert b"extprod_rotate_kernel" in blob and b"keyswitch_kernel" in blob
+    assert b"extprod_rotate_kernel" in blob and b"keyswitch_mfma" in blob and b"forward_fourier_kernel" in blob
 
 
 def test_product_does_not_reference_the_oracle():
