@@ -88,6 +88,11 @@ def main():
     ap.add_argument("--decrypt", action="store_true", help="time Server::aes_decrypt (BASELINE configs[4] path) instead of aes_encrypt")
     args = ap.parse_args()
 
+    # host-side Client work (key generation, encryption of the synthetic inputs) is OpenMP code: give every rank
+    # its share of the cores instead of letting N ranks oversubscribe the node
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // max(1, local_world))))
+
     import torch
     import torch.distributed as dist
 
