@@ -21,6 +21,10 @@ VARIANTS = {
     "r2_pf3": ["-DPBS_R=2", "-DEP_PREFETCH=3"],
     "r1": ["-DPBS_R=1"],
     "late_barrier": ["-DEP_LATE_BARRIER"],
+    "macprio0": ["-DEP_MAC_PRIO=0"],
+    "xpose_prio0": ["-DFFT_XPOSE_PRIO=0"],
+    "stage_prio": ["-DEP_STAGE_PRIO=2"],
+    "macprio2": ["-DEP_MAC_PRIO=2"],
     "old_conv": ["-DEP_OLD_CONV"],
     "pf1": ["-DEP_PREFETCH=1"],
     "pf2": ["-DEP_PREFETCH=2"],
