@@ -509,6 +509,23 @@ void orc_cbs_pbs(const orc_keys *K, const uint64_t *lwe_small, int lvl, uint64_t
     free(tmp);
 }
 
+/* batched forms for the parity tests (one independent unit per OpenMP task) */
+void orc_cbs_pbs_batch(const orc_keys *K, const uint64_t *lwe_small, int64_t m, int lvl, uint64_t *lwe_out)
+{
+    const orc_params *p = &K->p;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t q = 0; q < m; ++q)
+        orc_cbs_pbs(K, lwe_small + (size_t)q * (p->n + 1), lvl, lwe_out + (size_t)q * (BIG(p) + 1));
+}
+
+void orc_keyswitch_batch(const orc_keys *K, const uint64_t *in, int64_t m, uint64_t *out)
+{
+    const orc_params *p = &K->p;
+#pragma omp parallel for schedule(static)
+    for (int64_t q = 0; q < m; ++q)
+        orc_keyswitch(K, in + (size_t)q * (BIG(p) + 1), out + (size_t)q * (p->n + 1));
+}
+
 /* ------------------------------------------------------------------------- */
 /* K3: private functional packing keyswitch                    */
 /* ------------------------------------------------------------------------- */

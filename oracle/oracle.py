@@ -61,6 +61,8 @@ def lib():
             "orc_keyswitch": (None, [vp, u64p, u64p]),
             "orc_cbs_pbs": (None, [vp, u64p, ctypes.c_int, u64p]),
             "orc_pfpks": (None, [vp, ctypes.c_int, u64p, u64p]),
+            "orc_cbs_pbs_batch": (None, [vp, u64p, ctypes.c_int64, ctypes.c_int, u64p]),
+            "orc_keyswitch_batch": (None, [vp, u64p, ctypes.c_int64, u64p]),
             "orc_circuit_bootstrap": (None, [vp, u64p, u64p]),
             "orc_wopbs_batch": (None, [vp, u64p, ctypes.c_int, ctypes.c_int, u64p, ctypes.c_int, ctypes.c_int, u64p, u64p, u64p, u64p]),
             "orc_get_tables": (None, [u8p, u8p]),
@@ -190,16 +192,14 @@ class Oracle:
         p = self.params
         x = np.ascontiguousarray(lwe_in, dtype=np.uint64).reshape(-1, p.big1)
         out = np.empty((x.shape[0], p.n + 1), dtype=np.uint64)
-        for i in range(x.shape[0]):
-            lib().orc_keyswitch(self._h, _u64(x[i]), _u64(out[i]))
+        lib().orc_keyswitch_batch(self._h, _u64(x), x.shape[0], _u64(out))
         return out.reshape(lwe_in.shape[:-1] + (p.n + 1,))
 
     def cbs_pbs(self, lwe_small: np.ndarray, level: int = 1) -> np.ndarray:
         p = self.params
         x = np.ascontiguousarray(lwe_small, dtype=np.uint64).reshape(-1, p.n + 1)
         out = np.empty((x.shape[0], p.big1), dtype=np.uint64)
-        for i in range(x.shape[0]):
-            lib().orc_cbs_pbs(self._h, _u64(x[i]), level, _u64(out[i]))
+        lib().orc_cbs_pbs_batch(self._h, _u64(x), x.shape[0], level, _u64(out))
         return out.reshape(lwe_small.shape[:-1] + (p.big1,))
 
     def pfpks(self, lwe_in: np.ndarray) -> np.ndarray:

@@ -36,8 +36,9 @@ def test_k1_keyswitch(which, m, request):
     assert np.array_equal(out, kit.oracle.keyswitch(x))
 
 
-@pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 8), ("toy", 21), ("opt", 1), ("opt", 7)])
+@pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 8), ("toy", 21), ("toy", 530), ("opt", 1), ("opt", 7), ("opt", 520)])
 def test_k2_blind_rotation(which, m, request):
+    # m <= 512 runs the one-ciphertext-per-workgroup latency form, larger batches 3 (8 for the toy set) per workgroup
     kit = request.getfixturevalue(which)
     p, E = kit.params, kit.engine()
     x, bits = _inputs(kit, m, 20 + m)

@@ -20,6 +20,9 @@
 
 #define FHEAES_VERSION_STR "fheaes-mi355x 0.1 (gfx950)"
 #define MAX_CHUNK_BITS 32768ull
+#ifndef SMALL_BATCH_BITS
+#define SMALL_BATCH_BITS 512ull    /* at most 2 one-ciphertext workgroups per CU */
+#endif
 
 namespace {
 
@@ -346,7 +349,11 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
     a.out = out; a.count = m; a.iters = c->n; a.lwe_in = lwe_small;
     const uint64_t half_delta = 1ull << (64 - c->p.cbs_base_log * level - 1);
     a.tv_const = (uint64_t)0 - half_delta; a.body_shift = 1ull << 62; a.post_add = half_delta;
-    if (c->k1 == 5) {
+    if (c->k1 == 5 && m <= SMALL_BATCH_BITS) {
+        // latency regime (key expansion, counter add, one block): one ciphertext per workgroup spreads the batch
+        // over more CUs and shortens the multiply-accumulate of every iteration; same arithmetic, same bits
+        hipLaunchKernelGGL((extprod_rotate_kernel<5, 5, 8, 1, false>), dim3((unsigned)m), dim3(EP_THREADS), 0, c->stream, a);
+    } else if (c->k1 == 5) {
 #ifndef PBS_R
 #define PBS_R 3
 #endif
