@@ -35,6 +35,12 @@ def test_128_ctr_blocks_param_opt(opt, opt_server):
     out = d_st.cpu().numpy().view(np.uint64)
     for i in range(n):
         assert c.decrypt_u128(out[i]) == aes_clear.aes128_encrypt_block(key, IV + i), "block %d" % i
+    # noise budget over all 16,384 output bits: outputs carry one fresh WoPBS result + one round key (2 addends);
+    # the decision threshold is 2^62 (README.md:175-180 of the reference: p_fail 2^-64 at 5 addends)
+    bits, ph = c.decrypt_bits(out, return_phase=True)
+    err = (ph - (bits.astype(np.uint64) << np.uint64(63))).astype(np.int64)
+    assert np.abs(err).max() < 1 << 59, "max |noise| = 2^%.1f" % np.log2(float(np.abs(err).max()))
+    assert np.abs(err).std() < 1 << 56
     # determinism at full size: a second launch on the same inputs gives the same words
     d_st2 = torch.from_numpy(states.view(np.int64)).cuda()
     torch.cuda.synchronize()
