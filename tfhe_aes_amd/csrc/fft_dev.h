@@ -92,6 +92,13 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that waits for this wave's LDS traffic only (a plain __syncthreads() also drains
+// vmcnt, which would serialise global loads that were issued early on purpose).
+__device__ __forceinline__ void wg_barrier_lds_only()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // 16 x 16 transpose of the group's complex tile through LDS: lane `b` gives x[row] for every
 // row and receives tile[b][col] for every col.
 __device__ __forceinline__ void group_transpose(double (&xr)[16], double (&xi)[16], double *tile, int b)

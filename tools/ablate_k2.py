@@ -20,6 +20,12 @@ VARIANTS = {
     "r2": ["-DPBS_R=2"],
     "r2_pf3": ["-DPBS_R=2", "-DEP_PREFETCH=3"],
     "r1": ["-DPBS_R=1"],
+    "sched_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "sched_memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
+    "early1": ["-DEP_EARLY_LOAD=1"],
+    "early2": ["-DEP_EARLY_LOAD=2"],
+    "early2_pf3": ["-DEP_EARLY_LOAD=2", "-DEP_PREFETCH=3"],
+    "early3_pf3": ["-DEP_EARLY_LOAD=3", "-DEP_PREFETCH=3"],
     "late_barrier": ["-DEP_LATE_BARRIER"],
     "macprio0": ["-DEP_MAC_PRIO=0"],
     "xpose_prio0": ["-DFFT_XPOSE_PRIO=0"],
