@@ -105,3 +105,15 @@ def test_noise_budget_of_the_schedule(toy):
     bits, ph = c.decrypt_bits(y, return_phase=True)
     err = (ph - (bits.astype(np.uint64) << np.uint64(63))).astype(np.int64)
     assert np.abs(err).max() * 5 < 1 << 61
+
+
+def test_server_keys_roundtrip_through_a_file(toy, tmp_path):
+    from tfhe_aes_amd import PARAM_OPT
+    from tfhe_aes_amd.client import ServerKeys
+
+    f = tmp_path / "keys.npz"
+    toy.keys.save(f)
+    back = ServerKeys.load(f, toy.params)
+    assert np.array_equal(back.ksk, toy.keys.ksk) and np.array_equal(back.bsk, toy.keys.bsk) and np.array_equal(back.pfpksk, toy.keys.pfpksk)
+    with pytest.raises(ValueError):
+        ServerKeys.load(f, PARAM_OPT)

@@ -62,6 +62,26 @@ class ServerKeys:
     bsk: np.ndarray      # [n][pbs_level][k+1][k+1][N]   standard domain
     pfpksk: np.ndarray   # [k+1][kN+1][pfks_level][(k+1)N]
 
+    # The reference never serialises anything; these two helpers exist so that keys produced
+    # elsewhere can be fed to the engine.  Plain .npz of uint64 arrays (no pickle), layouts as in include/fheaes.h.
+    def save(self, path) -> None:
+        p = self.params
+        shape = np.array([p.lwe_dimension, p.glwe_dimension, p.polynomial_size, p.pbs_base_log, p.pbs_level, p.ks_base_log,
+                          p.ks_level, p.pfks_base_log, p.pfks_level, p.cbs_base_log, p.cbs_level], dtype=np.uint32)
+        np.savez(path, shape=shape, ksk=self.ksk, bsk=self.bsk, pfpksk=self.pfpksk)
+
+    @staticmethod
+    def load(path, params: WopbsParameters) -> "ServerKeys":
+        with np.load(path, allow_pickle=False) as z:
+            want = [params.lwe_dimension, params.glwe_dimension, params.polynomial_size, params.pbs_base_log, params.pbs_level,
+                    params.ks_base_log, params.ks_level, params.pfks_base_log, params.pfks_level, params.cbs_base_log, params.cbs_level]
+            if list(map(int, z["shape"])) != want:
+                raise ValueError("key file was generated for a different parameter set")
+            keys = ServerKeys(params, z["ksk"].astype(np.uint64), z["bsk"].astype(np.uint64), z["pfpksk"].astype(np.uint64))
+        if (keys.ksk.size, keys.bsk.size, keys.pfpksk.size) != (params.ksk_words, params.bsk_words, params.pfpksk_words):
+            raise ValueError("key file has the wrong array sizes")
+        return keys
+
 
 def u128_to_bytes(x: int) -> list[int]:
     """state byte i = bits [8*(15-i), 8*(16-i)) of the u128 (client.rs:126-129)."""
