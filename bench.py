@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--decrypt", action="store_true", help="time Server::aes_decrypt (BASELINE configs[4] path) instead of aes_encrypt")
+    ap.add_argument("--ctr-add", action="store_true",
+                    help="time the reference's whole CTR iteration (main.rs:59-61): Server::add_scalar(iv, i) on the GPU, then aes_encrypt")
     args = ap.parse_args()
 
     # host-side Client work (key generation, encryption of the synthetic inputs) is OpenMP code: give every rank
@@ -146,10 +148,15 @@ def main():
     # ---- this rank's counter blocks (pre-incremented client side; Server::add_scalar is timed apart) --
     lo, hi = shard_blocks(args.blocks * world, world, rank)
     counters = [(IV + i) & ((1 << 128) - 1) for i in range(lo, hi)]
-    host_state = np.stack([client.encrypt_u128(c) for c in counters])
-    state = torch.from_numpy(host_state.view(np.int64)).to(dev)
-    del host_state
     n_blocks = hi - lo
+    if args.ctr_add:
+        iv_ct = torch.from_numpy(client.encrypt_u128(IV).view(np.int64)).to(dev)
+        state = iv_ct.unsqueeze(0).repeat(n_blocks, 1, 1, 1).contiguous()        # encrypted_iv.clone() per block (main.rs:59)
+        iv_states = state.clone()
+    else:
+        host_state = np.stack([client.encrypt_u128(c) for c in counters])
+        state = torch.from_numpy(host_state.view(np.int64)).to(dev)
+        del host_state
     eng.reserve(n_blocks * 128)
     torch.cuda.synchronize()
 
@@ -159,7 +166,15 @@ def main():
         torch.cuda.synchronize()
         eng.synchronize()
 
-    step = eng.aes_decrypt if args.decrypt else eng.aes_encrypt
+    crypt = eng.aes_decrypt if args.decrypt else eng.aes_encrypt
+    if args.ctr_add:
+        def step(rk_, state_, n_):
+            state_.copy_(iv_states)
+            torch.cuda.synchronize()
+            eng.add_scalar(state_, n_, list(range(lo, hi)))
+            crypt(rk_, state_, n_)
+    else:
+        step = crypt
     for _ in range(args.warmup):
         step(rk, state, n_blocks)
     eng.synchronize()
@@ -186,7 +201,7 @@ def main():
         for idx in sorted({0, n_blocks // 2, n_blocks - 1}):
             got = client.decrypt_u128(state[idx].cpu().numpy().view(np.uint64))
             want = counters[idx]
-            for _ in range(args.warmup + args.steps):
+            for _ in range(1 if args.ctr_add else args.warmup + args.steps):
                 want = aes128_decrypt_block(KEY, want) if args.decrypt else aes128_encrypt_block(KEY, want)
             if got != want:
                 verified = False
@@ -239,7 +254,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64+f64", "data": "synthetic",
             "config": {
-                "workload": ("configs[4] path: %d blocks per GPU, Server::aes_decrypt (2432 bit-CBS/block)" % args.blocks) if args.decrypt else
+                "workload": ("reference CTR iteration (main.rs:59-61): %d blocks per GPU, Server::add_scalar (143 bit-CBS/block, 16-step carry chain) + "
+                             "Server::aes_encrypt (1280 bit-CBS/block)" % args.blocks) if args.ctr_add else
+                            ("configs[4] path: %d blocks per GPU, Server::aes_decrypt (2432 bit-CBS/block)" % args.blocks) if args.decrypt else
                             ("configs[2]: %d CTR blocks per GPU, Server::aes_encrypt 10 rounds (1280 bit-CBS/block), "
                              "counters pre-incremented client-side" % args.blocks),
                 "params": p.name, "blocks_per_gpu": args.blocks, "total_blocks": total_blocks,
