@@ -59,3 +59,32 @@ def test_ctr_counter_add_param_opt(opt, opt_server):
     opt_server.add_scalar(st, [0x1FF, 0xFFFFFFFF])
     assert c.decrypt_u128(st[0]) == (IV + 0x1FF) % (1 << 128)
     assert c.decrypt_u128(st[1]) == (IV + 0xFFFFFFFF) % (1 << 128)
+
+
+def test_1024_ctr_blocks_on_one_gpu(opt, opt_server):
+    """BASELINE configs[3] total size (1,024 CTR blocks) on ONE GPU: 131,072 bits per round, processed in four
+    workspace chunks; every block must decrypt to AES-CTR (the 8-GPU run shards the same stream 128 per GPU)."""
+    import torch
+
+    c, p = opt.client, opt.params
+    key = c.key
+    rk = opt_server.aes_key_expansion(c.encrypt_u128(key))
+    n = 1024
+    bits = np.zeros((n, 16, 8), dtype=np.uint8)
+    for i in range(n):
+        v = (IV + i) & ((1 << 128) - 1)
+        for byte in range(16):
+            bv = (v >> (8 * (15 - byte))) & 0xFF
+            bits[i, byte] = [(bv >> j) & 1 for j in range(8)]
+    states = c.encrypt_bits(bits)                                   # one call: [1024][16][8][kN+1]
+    d_rk = torch.from_numpy(rk.view(np.int64)).cuda()
+    d_st = torch.from_numpy(states.view(np.int64)).cuda()
+    del states
+    torch.cuda.synchronize()
+    opt_server.aes_encrypt(d_rk, d_st)
+    opt_server.synchronize()
+    out = d_st.cpu().numpy().view(np.uint64)
+    got = c.decrypt_bytes(out)                                      # [1024][16]
+    for i in range(n):
+        want = aes_clear.aes128_encrypt_block(key, (IV + i) & ((1 << 128) - 1))
+        assert [int(x) for x in got[i]] == [(want >> (8 * (15 - b))) & 0xFF for b in range(16)], "block %d" % i
