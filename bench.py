@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--params", default="opt", choices=["opt", "toy"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo lets several ranks share one GPU to rehearse the N>1 path on a 1-GPU box")
     ap.add_argument("--decrypt", action="store_true", help="time Server::aes_decrypt (BASELINE configs[4] path) instead of aes_encrypt")
     ap.add_argument("--ctr-add", action="store_true",
                     help="time the reference's whole CTR iteration (main.rs:59-61): Server::add_scalar(iv, i) on the GPU, then aes_encrypt")
@@ -112,11 +114,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     # ---- keys: generated on rank 0, broadcast once over RCCL/xGMI --------------------------------
     client = Client(args.blocks * world, IV, KEY, params=p, seed=0xAE50001)     # secret keys: same seed on every rank
@@ -127,7 +133,7 @@ def main():
     dkeys = broadcast_keys(p, keys, dev, src=0)
     torch.cuda.synchronize()
     bcast_s = time.time() - t0
-    eng = _native.Engine(p, device=local_rank)
+    eng = _native.Engine(p, device=dev_index)
     eng.upload_keys(*dkeys)
     del dkeys
     torch.cuda.empty_cache()
