@@ -15,6 +15,7 @@
 #include "fheaes.h"
 #include "fft_dev.h"
 #include "kern_extprod.h"
+#include "kern_blindrot_latency.h"
 #include "kern_keyswitch.h"
 #include "kern_linear.h"
 
@@ -349,7 +350,14 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
     a.out = out; a.count = m; a.iters = c->n; a.lwe_in = lwe_small;
     const uint64_t half_delta = 1ull << (64 - c->p.cbs_base_log * level - 1);
     a.tv_const = (uint64_t)0 - half_delta; a.body_shift = 1ull << 62; a.post_add = half_delta;
-    if (c->k1 == 5 && m <= SMALL_BATCH_BITS) {
+#ifndef LATENCY_BATCH_BITS
+#define LATENCY_BATCH_BITS 256ull      /* at most one 512-thread workgroup per CU */
+#endif
+    if (m <= LATENCY_BATCH_BITS) {
+        // latency regime: one ciphertext per 512-thread workgroup, all levels transformed at once (kern_blindrot_latency.h)
+        if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate_latency_kernel<5, 5, 8>), dim3((unsigned)m), dim3(BL_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((blind_rotate_latency_kernel<2, 5, 8>), dim3((unsigned)m), dim3(BL_THREADS), 0, c->stream, a);
+    } else if (c->k1 == 5 && m <= SMALL_BATCH_BITS) {
         // latency regime (key expansion, counter add, one block): one ciphertext per workgroup spreads the batch
         // over more CUs and shortens the multiply-accumulate of every iteration; same arithmetic, same bits
         hipLaunchKernelGGL((extprod_rotate_kernel<5, 5, 8, 1, false>), dim3((unsigned)m), dim3(EP_THREADS), 0, c->stream, a);
