@@ -260,6 +260,14 @@ void orc_fft_fwd_int(const int64_t *poly, double *out_interleaved /*[256][2]*/)
     for (int t = 0; t < HALF; ++t) { out_interleaved[2 * t] = fr[t]; out_interleaved[2 * t + 1] = fi[t]; }
 }
 
+/* inverse transform of one Fourier image (natural order, interleaved), rounded to the torus and added into acc[512] */
+void orc_fft_inv_add(const double *f_interleaved /*[256][2]*/, uint64_t *acc /*[512]*/)
+{
+    double fr[HALF], fi[HALF];
+    for (int t = 0; t < HALF; ++t) { fr[t] = f_interleaved[2 * t]; fi[t] = f_interleaved[2 * t + 1]; }
+    nega_inv_add(fr, fi, acc);
+}
+
 void orc_fft_fwd_torus(const uint64_t *poly, double *out_interleaved)
 {
     double fr[HALF], fi[HALF];

@@ -10,12 +10,20 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "fheaes.h"
 #include "fft_dev.h"
 #include "kern_extprod.h"
 #include "kern_blindrot_latency.h"
+#include "kern_blindrot16.h"
+#ifndef PBS_FORM32
+#define PBS_FORM32 0            /* developer build: the 32-lane experiment under tools/experiments (measured slower) */
+#endif
+#if PBS_FORM32
+#include "../../tools/experiments/kern_blindrot32.h"
+#endif
 #include "kern_keyswitch.h"
 #include "kern_linear.h"
 
@@ -192,7 +200,7 @@ struct fheaes_ctx {
     uint64_t *lutset_d[LUTSET_COUNT] = {};
     int lutset_n[LUTSET_COUNT] = {};
     // workspace
-    DevBuf ws_small, ws_pbs, ws_ggsw, ws_ggswf, ws_vp, ws_tmp_a, ws_tmp_b, ws_luts, ws_misc, ws_digits;
+    DevBuf ws_small, ws_pbs, ws_ggsw, ws_ggswf, ws_vp, ws_tmp_a, ws_tmp_b, ws_luts, ws_misc, ws_digits, ws_park;
     // profiling
     bool prof = false;
     struct Pending { hipEvent_t a, b; int stage; };
@@ -281,6 +289,31 @@ struct StageScope {
     }
 };
 
+#ifdef EP_STAMPS
+// developer build: per-phase cycle counts written by the blind-rotation kernels
+struct StampReport {
+    fheaes_ctx *c; unsigned long long *d = nullptr; size_t waves; const char *const *names;
+    StampReport(fheaes_ctx *ctx, size_t waves_, const char *const *names_) : c(ctx), waves(waves_), names(names_)
+    {
+        (void)hipMalloc((void **)&d, waves * EP_NPH * 8);
+        (void)hipMemsetAsync(d, 0, waves * EP_NPH * 8, c->stream);
+    }
+    ~StampReport()
+    {
+        std::vector<unsigned long long> h(waves * EP_NPH);
+        (void)hipMemcpyAsync(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(d);
+        double tot[EP_NPH] = {}, all = 0;
+        for (size_t w = 0; w < waves; ++w) for (int i = 0; i < EP_NPH; ++i) tot[i] += (double)h[w * EP_NPH + i];
+        for (int i = 0; i < EP_NPH; ++i) all += tot[i];
+        fprintf(stderr, "K2 phase cycles per wave per iteration (s_memtime ticks, avg over %zu waves):\n", waves);
+        for (int i = 0; i < EP_NPH; ++i) fprintf(stderr, "  %-32s %9.0f  %5.1f %%\n", names[i], tot[i] / ((double)waves * c->n), 100.0 * tot[i] / all);
+        fprintf(stderr, "  %-32s %9.0f\n", "total", all / ((double)waves * c->n));
+    }
+};
+#endif
+
 // ---- kernel launchers ------------------------------------------------------------------------
 int launch_keyswitch(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *out)
 {
@@ -361,16 +394,77 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         // latency regime (key expansion, counter add, one block): one ciphertext per workgroup spreads the batch
         // over more CUs and shortens the multiply-accumulate of every iteration; same arithmetic, same bits
         hipLaunchKernelGGL((extprod_rotate_kernel<5, 5, 8, 1, false>), dim3((unsigned)m), dim3(EP_THREADS), 0, c->stream, a);
+#if PBS_FORM32
+    } else if (c->k1 == 5 || c->k1 == 2) {
+        // throughput form: 32 lanes per polynomial, 4 waves per SIMD (kern_blindrot32.h)
+        const unsigned R32 = c->k1 == 5 ? 3 : 8;
+        const unsigned grid32 = (unsigned)((m + R32 - 1) / R32);
+        TRY(ensure(c, c->ws_park, (size_t)grid32 * 8 * BR32_THREADS * 16));
+        a.park = (uint64_t *)c->ws_park.p;
+#ifdef EP_STAMPS
+        static const char *names32[EP_NPH] = {"stage+rotate+decomp_first", "decomp_next", "twist+step A", "pre-trip barrier", "trip1+step B",
+                                              "trip2+step C+digit stores", "exchange barrier", "MAC", "products exchange", "inverse fft", "convert+add", "loop head"};
+        StampReport rep(c, (size_t)grid32 * 8, names32);
+        a.stamps = rep.d;
+#endif
+        if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate32_kernel<5, 5, 8, 3>), dim3(grid32), dim3(BR32_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((blind_rotate32_kernel<2, 5, 8, 8>), dim3(grid32), dim3(BR32_THREADS), 0, c->stream, a);
+#endif
+#ifndef PBS_FORM16
+#define PBS_FORM16 1
+#endif
+#if PBS_FORM16
+    } else {
+        // throughput form (kern_blindrot16.h): accumulator parked in HBM between uses, key rows prefetched across the transform
+        const unsigned R16 = c->k1 == 5 ? 3 : 8;
+        const unsigned grid16 = (unsigned)((m + R16 - 1) / R16);
+        TRY(ensure(c, c->ws_park, (size_t)grid16 * BR16_PARK_WORDS_PER_WG * 8));
+        a.park = (uint64_t *)c->ws_park.p;
+#ifdef EP_STAMPS
+        static const char *names16[EP_NPH] = {"stage+rotate+decomp_first", "decomp_next", "fwd head", "pre-level barrier", "fwd tail (transpose+dft16)",
+                                              "digit stores+late loads", "exchange barrier", "MAC", "products exchange", "inverse fft", "convert+add", "loop head"};
+        StampReport rep(c, (size_t)grid16 * 4, names16);
+        a.stamps = rep.d;
+#endif
+        if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate16_kernel<5, 5, 8, 3>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
+        else hipLaunchKernelGGL((blind_rotate16_kernel<2, 5, 8, 8>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
+    }
+#else
     } else if (c->k1 == 5) {
 #ifndef PBS_R
 #define PBS_R 3
 #endif
         constexpr int R = PBS_R;
+#ifdef EP_STAMPS
+        const unsigned grid_s = (unsigned)((m + R - 1) / R);
+        unsigned long long *st_d = nullptr;
+        (void)hipMalloc((void **)&st_d, (size_t)grid_s * 4 * EP_NPH * 8);
+        (void)hipMemsetAsync(st_d, 0, (size_t)grid_s * 4 * EP_NPH * 8, c->stream);
+        a.stamps = st_d;
+#endif
         hipLaunchKernelGGL((extprod_rotate_kernel<5, 5, 8, R, false>), dim3((unsigned)((m + R - 1) / R)), dim3(EP_THREADS), 0, c->stream, a);
+#ifdef EP_STAMPS
+        {
+            std::vector<unsigned long long> h((size_t)grid_s * 4 * EP_NPH);
+            (void)hipMemcpyAsync(h.data(), st_d, h.size() * 8, hipMemcpyDeviceToHost, c->stream);
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipFree(st_d);
+            static const char *names[EP_NPH] = {"rotate+decomp_first", "decomp_next", "fwd head", "pre-level barrier", "fwd tail (transpose+dft16)",
+                                                "digit stores+early loads", "exchange barrier", "MAC", "products exchange", "inverse fft", "convert+add", "loop head"};
+            double tot[EP_NPH] = {}, all = 0;
+            for (size_t w = 0; w < (size_t)grid_s * 4; ++w) for (int i = 0; i < EP_NPH; ++i) tot[i] += (double)h[w * EP_NPH + i];
+            for (int i = 0; i < EP_NPH; ++i) all += tot[i];
+            fprintf(stderr, "K2 phase cycles per wave per iteration (s_memtime ticks, avg over %u waves):\n", grid_s * 4);
+            for (int i = 0; i < EP_NPH; ++i)
+                fprintf(stderr, "  %-28s %9.0f  %5.1f %%\n", names[i], tot[i] / ((double)grid_s * 4 * c->n), 100.0 * tot[i] / all);
+            fprintf(stderr, "  %-28s %9.0f\n", "total", all / ((double)grid_s * 4 * c->n));
+        }
+#endif
     } else {
         constexpr int R = 8;
         hipLaunchKernelGGL((extprod_rotate_kernel<2, 5, 8, R, false>), dim3((unsigned)((m + R - 1) / R)), dim3(EP_THREADS), 0, c->stream, a);
     }
+#endif
     HIP_TRY(c, hipGetLastError());
     return FHEAES_OK;
 }
@@ -584,7 +678,8 @@ void fheaes_destroy(fheaes_ctx *c)
     for (auto &pe : c->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : c->free_events) (void)hipEventDestroy(ev);
     void *ptrs[] = {c->ksk_frag, c->pfpksk_frag, c->bskf, c->psi_d, c->tw_d, c->ws_digits.p,
-                    c->ws_small.p, c->ws_pbs.p, c->ws_ggsw.p, c->ws_ggswf.p, c->ws_vp.p, c->ws_tmp_a.p, c->ws_tmp_b.p, c->ws_luts.p, c->ws_misc.p};
+                    c->ws_small.p, c->ws_pbs.p, c->ws_ggsw.p, c->ws_ggswf.p, c->ws_vp.p, c->ws_tmp_a.p, c->ws_tmp_b.p, c->ws_luts.p, c->ws_misc.p,
+                    c->ws_park.p};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < LUTSET_COUNT; ++s) if (c->lutset_d[s]) (void)hipFree(c->lutset_d[s]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -55,7 +55,18 @@ struct ExtProdArgs {
     uint32_t lut_per_input;
     uint32_t inst_per_input;    // n_luts * bits
     uint32_t wg_per_input;      // ceil(inst_per_input / R)
+    uint64_t *park;             // kern_blindrot32.h: accumulator parking space, 64 KB per workgroup
+#ifdef EP_STAMPS
+    unsigned long long *stamps; // developer build: per-wave cycles per phase [grid][4 waves][EP_NPH]
+#endif
 };
+
+#ifdef EP_STAMPS
+#define EP_NPH 12
+#define EP_STAMP(ph) do { unsigned long long t__ = __builtin_readcyclecounter(); ph_cyc[ph] += t__ - t_last; t_last = t__; } while (0)
+#else
+#define EP_STAMP(ph) do { } while (0)
+#endif
 
 template <int K1, int LEVELS, int BASE_LOG, int R, bool VP>
 #ifndef EP_MIN_WAVES
@@ -122,6 +133,11 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
         }
     }
     __syncthreads();   // tables visible
+#ifdef EP_STAMPS
+    unsigned long long ph_cyc[EP_NPH];
+    for (int i = 0; i < EP_NPH; ++i) ph_cyc[i] = 0;
+    unsigned long long t_last = __builtin_readcyclecounter();
+#endif
 
     const size_t ggsw_stride = (size_t)LEVELS * K1 * K1 * FHE_H;   // double2 elements per GGSW
 
@@ -137,6 +153,7 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
         }
 
         // ---- d = acc * X^t - acc, first decomposition level -----------------------------------
+        EP_STAMP(11);
         uint64_t *stage = reinterpret_cast<uint64_t *>(tile);
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
@@ -160,6 +177,7 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
             if ((a & (EP_ROT_CHUNK - 1)) == EP_ROT_CHUNK - 1) __builtin_amdgcn_sched_barrier(0);
         }
         wave_lds_sync();
+        EP_STAMP(0);
 
         double fr[R][K1], fi[R][K1];
 #pragma unroll
@@ -174,6 +192,7 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
 #ifndef EP_LATE_BARRIER
             if (tiles_busy) __syncthreads();
 #endif
+            EP_STAMP(3);
             // first half of the transform needs no tile; the barrier that frees the tiles (other threads
             // may still be reading the previous level's digits) sits as late as possible
 #ifndef ABL_NO_FFT
@@ -182,9 +201,11 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
 #ifdef EP_LATE_BARRIER
             if (tiles_busy) __syncthreads();
 #endif
+            EP_STAMP(2);
 #ifndef ABL_NO_FFT
             nega_fwd_tail(xr, xi, tile, b, fc);
 #endif
+            EP_STAMP(4);
             const double2 *Gl = G + (size_t)l * K1 * K1 * FHE_H + tid;
 #if EP_EARLY_LOAD
             // Store a few transformed digits, start a GGSW row into the registers that just died, repeat: the
@@ -212,7 +233,9 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
                 *reinterpret_cast<double2 *>(tile + 2 * (b + 16 * k2)) = v;
             }
             __builtin_amdgcn_sched_barrier(0);
+            EP_STAMP(5);
             wg_barrier_lds_only();
+            EP_STAMP(6);
 #else
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
@@ -273,6 +296,7 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
             __builtin_amdgcn_s_setprio(0);
 #endif
 #endif
+            EP_STAMP(7);
         };
         level_body(LEVELS - 1, false);
 #pragma unroll 1
@@ -282,6 +306,7 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
                 xr[a] = (double)decompose_next<BASE_LOG>(st_lo[a]);
                 xi[a] = (double)decompose_next<BASE_LOG>(st_hi[a]);
             }
+            EP_STAMP(1);
             level_body(l, true);
         }
 
@@ -301,15 +326,22 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
             xr[k2] = v.x; xi[k2] = v.y;
         }
         wave_lds_sync();
+        EP_STAMP(8);
 #ifndef ABL_NO_FFT
         nega_inv(xr, xi, psi, tw, tile, b, fc);
 #endif
+        EP_STAMP(9);
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             lo[a] += torus_from_double(xr[a]);
             hi[a] += torus_from_double(xi[a]);
         }
+        EP_STAMP(10);
     }
+#ifdef EP_STAMPS
+    if (A.stamps && (tid & 63) == 0)
+        for (int i = 0; i < EP_NPH; ++i) A.stamps[((size_t)blockIdx.x * 4 + (tid >> 6)) * EP_NPH + i] = ph_cyc[i];
+#endif
 
     // ---- sample extract coefficient 0 ---------------------------------------------
     if (owner && valid) {

@@ -17,6 +17,24 @@ from tfhe_aes_amd.client import Client  # noqa: E402
 
 VARIANTS = {
     "base": [],
+    "stamps": ["-DEP_STAMPS"],
+    "old16": ["-DPBS_FORM16=0"],
+    "form32": ["-DPBS_FORM32=1"],
+    "b16_prio0": ["-DBR16_MAC_PRIO=0"],
+    "b16_noload": ["-DBR16_ABL_NOLOAD"],
+    "b16_nomac": ["-DBR16_ABL_NOMAC"],
+    "b16_nomac_noload": ["-DBR16_ABL_NOMAC", "-DBR16_ABL_NOLOAD"],
+    "b16_nofft": ["-DBR16_ABL_NOFFT"],
+    "b16_noxpose": ["-DBR16_ABL_NOXPOSE"],
+    "b16_nofft_nomac_noload": ["-DBR16_ABL_NOFFT", "-DBR16_ABL_NOMAC", "-DBR16_ABL_NOLOAD"],
+    "b16_xprio0": ["-DFFT_XPOSE_PRIO=0"],
+    "one_wg": ["-DBR32_PAD_CPLX=2048"],
+    "one_wg_stamps": ["-DBR32_PAD_CPLX=2048", "-DEP_STAMPS"],
+    "b32_prio0": ["-DBR32_MAC_PRIO=0"],
+    "b32_pf1": ["-DBR32_PREFETCH=1"],
+    "b32_pf3": ["-DBR32_PREFETCH=3"],
+    "b32_nopark": ["-DBR32_PARK=0"],
+    "b32_w3": ["-DBR32_MIN_WAVES=3"],
     "r2": ["-DPBS_R=2"],
     "r2_pf3": ["-DPBS_R=2", "-DEP_PREFETCH=3"],
     "r1": ["-DPBS_R=1"],
