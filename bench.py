@@ -8,9 +8,14 @@ rank's BLOCKS counter blocks, already resident in HBM.  Workload = BASELINE.json
 1,024 blocks), keys are broadcast once over RCCL and there is no data-path collective: "weak" scaling.
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline      dominant kernel (blind rotation): algorithmic HBM bytes per launch / measured launch time
+  roofline      dominant kernel (blind rotation).  It leads with the roof that BINDS at this batch size (f64 vector
+                arithmetic: algorithmic flops per launch / measured launch time vs the f64 VALU peak); the HBM view
+                (algorithmic bytes per launch / launch time vs 8 TB/s) is nested under "hbm".  "traffic" (measured
+                HBM-side bytes per launch) is filled only from a rocprofv3 --pmc summary under profiles/ that was
+                taken from the SAME engine sources (sha256 recorded in the summary), else null.
   cpu_baseline  the CPU oracle ("port" of the reference algorithm; the reference itself is Rust + the
-                un-vendored tfhe 0.11.2 crate and cannot be built here) timed on this host's cores
+                un-vendored tfhe 0.11.2 crate and cannot be built here) timed on this host's cores: one thread
+                (S-Box and a whole block, extrapolated from 16 S-Boxes) and all cores
 """
 from __future__ import annotations
 
@@ -52,14 +57,31 @@ def usable_cores() -> int:
 
 
 def cpu_baseline(p, keys, client, seconds_hint: float = 20.0):
-    """time the oracle's many_sbox (one AES round of one block = 16 bytes = 128 bit-CBS) on all host cores"""
+    """the oracle (a C port of the reference's algorithm) timed on this host, bounded to ~10-30 s:
+      (i)  ONE thread: 16 many_sbox calls' worth (one AES round of one block = 16 bytes = 128 bit-CBS) -> ms per
+           S-Box, and a whole block by extrapolation (aes_encrypt = 160 byte-WoPBS; the reference's C1 run,
+           main.rs:48-64, adds key expansion = 200 and the counter add = 16 WoPBS, 15 of them 9 bits wide);
+      (ii) all usable cores, blocks in parallel over bytes (the reference runs blocks in parallel with rayon,
+           main.rs:55-64)."""
     from oracle import oracle as orc
 
     O = orc.Oracle(p, keys.ksk, keys.bsk, keys.pfpksk)
     cores = usable_cores()
-    orc.lib().orc_set_threads(cores)
     luts = orc.build_lutset(orc.LUTSET_ENC_ROUND)
     x = client.encrypt_bytes(list(range(16)))
+    # (i) single thread
+    orc.lib().orc_set_threads(1)
+    n1 = 16 if p.name == "PARAM_OPT" else 64
+    t0 = time.time()
+    O.wopbs_batch(x[:1], luts)                                  # one S-Box alone
+    one_sbox_s = time.time() - t0
+    t0 = time.time()
+    for i0 in range(0, n1, 16):
+        O.wopbs_batch(x, luts)
+    dt1 = time.time() - t0
+    sbox_1t_s = dt1 / n1
+    # (ii) all cores
+    orc.lib().orc_set_threads(cores)
     n_done, t0 = 0, time.time()
     while True:
         O.wopbs_batch(x, luts)
@@ -70,8 +92,16 @@ def cpu_baseline(p, keys, client, seconds_hint: float = 20.0):
     sbox_per_s = n_done / dt
     return {
         "value": sbox_per_s / 160.0, "unit": "blocks/s", "cores": cores, "kind": "port",
-        "sample": "%d many_sbox (byte-WoPBS, 3 LUTs) of the C oracle in %.1f s; blocks/s = S-Box/s / 160" % (n_done, dt),
+        "sample": "%d many_sbox (byte-WoPBS, 3 LUTs) of the C oracle on %d cores in %.1f s; blocks/s = S-Box/s / 160" % (n_done, cores, dt),
         "ms_per_sbox_per_core": 1000.0 * dt * cores / n_done,
+        "single_thread": {
+            "cores": 1, "ms_one_sbox_alone": 1000.0 * one_sbox_s, "ms_per_sbox": 1000.0 * sbox_1t_s,
+            "s_per_block_aes_encrypt": 160.0 * sbox_1t_s,
+            "s_per_block_reference_c1": (160.0 + 200.0 + 16.0 * 9.0 / 8.0) * sbox_1t_s,
+            "blocks_per_s": 1.0 / (160.0 * sbox_1t_s),
+            "sample": "%d many_sbox on one thread in %.1f s; a block is extrapolated: aes_encrypt = 160 byte-WoPBS, the reference's whole "
+                      "1-block run (main.rs:48-64: key expansion 200 + counter add 16 nine-bit + encrypt 160) = 378 S-Box equivalents" % (n1, dt1),
+        },
         "reference_published": "84 s per block single core (README.md:186), unknown hardware",
     }
 
@@ -110,8 +140,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch as `python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 bench.py --gpus %d ...` (one process per GPU)" % (world, args.gpus, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     dev_index = local_rank % torch.cuda.device_count()
@@ -200,6 +230,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- CPU baseline (rank 0, outside the timed region; the other ranks wait at the final barrier) -----------------
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(p, keys, client)
+
     # ---- verify a sample: decrypt == AES applied (warmup+steps) times to the counter -----------------
     verified = None
     if not args.no_verify:
@@ -245,15 +280,17 @@ def main():
         achieved_gbs = algo_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         flops = bits_per_launch * p.n * ext_product_flops(p)
         tflops = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        traffic = None
-        pmc = ROOT / "profiles" / "pmc_blind_rotate.json"
-        if pmc.exists():
+        # measured HBM-side bytes per launch: only from a PMC summary taken from these very engine sources
+        from tfhe_aes_amd import _build
+        traffic, traffic_src = None, None
+        for pmc in sorted((ROOT / "profiles").glob("*pmc_blind_rotate*.json")):
             try:
                 d = json.loads(pmc.read_text())
-                if d.get("bits_per_launch") == bits_per_launch and d.get("params") == p.name:
-                    traffic = d.get("hbm_bytes_per_launch")
+                if (d.get("engine_src_sha256") == _build.engine_source_hash() and d.get("bits_per_launch") == bits_per_launch
+                        and d.get("params") == p.name):
+                    traffic, traffic_src = d.get("hbm_bytes_per_launch"), pmc.name
             except Exception:
-                traffic = None
+                pass
         stage_ms = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
         line = {
             "metric": "AES-128 CTR blocks/sec (FHE)", "value": value, "unit": "blocks/s", "n_gpus": world,
@@ -274,20 +311,22 @@ def main():
                                         "note": "BASELINE configs[1]: 16 S-Box WoPBS (128 bit-CBS) in one call: latency of the 669-step rotation chain"},
             "stage_ms_per_step": stage_ms,
             "roofline": {
-                "kernel": "extprod_rotate_kernel (blind rotation, K2)", "bound": "hbm",
-                "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": traffic, "avg_launch_ms": avg_ms, "bits_per_launch": bits_per_launch,
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "note": "one pass over the 342.5 MB BSK per launch + per-bit I/O; at this batch the kernel is f64-VALU/LDS bound, see `compute`",
-                "compute": {"bound": "valu_f64", "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": tflops / F64_VALU_PEAK_TFLOPS, "flops_per_external_product": ext_product_flops(p)},
+                "kernel": "blind_rotate16_kernel (blind rotation, K2)", "bound": "valu_f64",
+                "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_VALU_PEAK_TFLOPS,
+                "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "bits_per_launch": bits_per_launch,
+                "algorithmic_flops_per_launch": flops, "flops_per_external_product": ext_product_flops(p),
+                "note": "at 16,384 bits per launch the kernel is bound by f64 vector issue (+ LDS and L1 fill time that do not overlap it), "
+                        "not by HBM: the BSK is read once per launch",
+                "hbm": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": algo_bytes,
+                        "note": "one pass over the 342.5 MB Fourier BSK per launch + per-bit I/O (5,360 B in, 16,392 B out)"},
             },
-            "setup_s": {"keygen": round(keygen_s, 2), "key_broadcast": round(bcast_s, 3),
+            "setup_s": {"keygen": round(keygen_s, 2), ("key_upload_h2d" if world == 1 else "key_broadcast_" + ("rccl" if args.backend == "nccl" else args.backend)): round(bcast_s, 3),
                         "aes_key_expansion": None if keyexp_s is None else round(keyexp_s, 3)},
         }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(p, keys, client)
-            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+            line["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -125,6 +125,50 @@ def test_device_resident_tensors_match_host_path(toy, toy_server):
         toy_server.aes_encrypt(rk, d_st)                   # mixed memory spaces are refused
 
 
+def test_device_tensors_with_host_luts(toy, toy_server):
+    """many_wopbs_without_padding on CUDA tensors with a host LUT list: the wrapper's device copy of the LUTs must be
+    complete before the engine's stream reads it and must stay alive until the engine is idle"""
+    import torch
+
+    c = toy.client
+    x = c.encrypt_bytes([0x11, 0xC4, 0x7E])
+    luts = list(orc.build_lutset(orc.LUTSET_DEC_MUL))
+    want = toy.oracle.wopbs_batch(x, np.stack(luts))
+    d_x = torch.from_numpy(x.view(np.int64)).cuda()
+    outs = []
+    for _ in range(3):                                       # several calls in flight, temporaries churn in between
+        outs.append(toy_server.many_wopbs_without_padding(d_x, luts))
+        junk = torch.full((luts[0].size * 4,), -1, dtype=torch.int64, device="cuda")   # would reuse a freed LUT block
+        del junk
+    toy_server.synchronize()
+    for o in outs:
+        assert np.array_equal(o.cpu().numpy().view(np.uint64), want)
+
+
+def test_add_scalar_then_encrypt_enqueued_without_sync(toy, toy_server):
+    """FHEAES_DEVICE calls only enqueue (fheaes.h): add_scalar + aes_encrypt on device tensors with ONE final
+    synchronize equal the host-path results"""
+    import torch
+
+    c = toy.client
+    iv = 0xF0F1F2F3F4F5F6F7F8F9FAFBFCFDFEFF
+    rk = toy.oracle.aes_key_expansion(c.encrypt_u128(c.key))
+    st = np.stack([c.encrypt_u128(iv)] * 2)
+    host = toy_server.aes_encrypt(rk, toy_server.add_scalar(st.copy(), [5, 0x1FF]))
+    d_rk = torch.from_numpy(rk.view(np.int64)).cuda()
+    d_a = torch.from_numpy(st.view(np.int64)).cuda()
+    d_b = torch.from_numpy(st.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    toy_server.add_scalar(d_a, [5, 0x1FF])
+    toy_server.add_scalar(d_b, [0x1FF, 5])                   # second call reuses the pinned counter staging
+    toy_server.aes_encrypt(d_rk, d_a)
+    toy_server.aes_encrypt(d_rk, d_b)
+    toy_server.synchronize()
+    a, b = d_a.cpu().numpy().view(np.uint64), d_b.cpu().numpy().view(np.uint64)
+    assert np.array_equal(a, host)
+    assert np.array_equal(b[0], host[1]) and np.array_equal(b[1], host[0])
+
+
 def test_many_sbox_param_opt(opt):
     """one AES round's worth of S-Boxes (16 bytes = 128 bit-CBS) at the reference's parameter set"""
     srv = Server(opt.keys, device=0, engine=opt.engine())
@@ -136,3 +180,26 @@ def test_many_sbox_param_opt(opt):
     for i, v in enumerate(vals):
         s = aes_clear.SBOX[v]
         assert list(dec[i]) == [s, aes_clear.mul2(s), aes_clear.mul3(s)]
+
+
+def test_full_block_bit_exact_param_opt(opt):
+    """One whole block at the reference's parameter set, every Server entry point word for word against the oracle:
+    aes_key_expansion (server.rs:107-167), aes_encrypt (:39-64), aes_decrypt (:67-105), add_scalar(0x1FF) (:172-274).
+    This is what pins the k=4 strides of the gather/add kernels, the 9-bit pack/unpack kernels and the 4-LUT packing;
+    the oracle side costs ~40 s on the GPU box's host cores."""
+    c, O = opt.client, opt.oracle
+    srv = Server(opt.keys, device=0, engine=opt.engine())
+    key, pt = c.key, 0x3243F6A8885A308D313198A2E0370734
+    ek, st = c.encrypt_u128(key), c.encrypt_u128(pt)
+    rk = srv.aes_key_expansion(ek)
+    rk_want = O.aes_key_expansion(ek)
+    assert np.array_equal(rk, rk_want)
+    enc = srv.aes_encrypt(rk, st.copy())
+    assert np.array_equal(enc, O.aes_encrypt(rk_want, st.copy()))
+    assert c.decrypt_u128(enc) == aes_clear.aes128_encrypt_block(key, pt)
+    dec = srv.aes_decrypt(rk, enc.copy())
+    assert np.array_equal(dec, O.aes_decrypt(rk_want, enc.copy()))
+    assert c.decrypt_u128(dec) == pt
+    ctr = srv.add_scalar(st.copy(), 0x1FF)
+    assert np.array_equal(ctr, O.add_scalar(st.copy(), 0x1FF))
+    assert c.decrypt_u128(ctr) == (pt + 0x1FF) % (1 << 128)

@@ -1,0 +1,54 @@
+"""bench.py's own N>1 code path under the driver's eyes: two ranks (fresh child processes of torch.distributed.run)
+share the one GPU of the test box over the gloo backend -- shard_blocks, broadcast_keys / broadcast_tensor, per-rank
+verification against AES-CTR and the MAX all-reduce of the elapsed time all run; only the transport differs from the
+8-GPU RCCL run (which this pool does not let a builder launch).  The children initialise the GPU themselves; nothing
+here re-execs a process that has touched it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_bench(nproc: int, extra):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", str(nproc), "--backend", "gloo", "--params", "toy"] + extra
+    res = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on rank 0, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_gloo():
+    line = _run_bench(2, ["--blocks", "2", "--steps", "1", "--warmup", "0"])
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["scaling"] == "weak"
+    assert line["verified_vs_aes"] is True
+    assert line["config"]["total_blocks"] == 4
+    assert line["unit"] == "blocks/s" and line["value"] > 0
+    assert "cpu_baseline" in line and line["cpu_baseline"]["kind"] == "port"        # present for every world size
+    assert line["roofline"]["bound"] == "valu_f64" and "hbm" in line["roofline"]
+    assert "key_broadcast_gloo" in line["setup_s"]
+
+
+def test_bench_refuses_world_size_mismatch():
+    """--gpus must equal WORLD_SIZE: a silent single-rank run of a "2 GPU" bench would be an invalid number"""
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--params", "toy", "--blocks", "1"], cwd=str(ROOT),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE" in (res.stderr + res.stdout)

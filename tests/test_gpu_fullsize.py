@@ -53,6 +53,35 @@ def test_128_ctr_blocks_param_opt(opt, opt_server):
         assert c.decrypt_u128(back[i]) == IV + i
 
 
+def test_32_block_decrypt_param_opt(opt, opt_server):
+    """BASELINE configs[4] shard size: 32 blocks per GPU through aes_decrypt (inverse S-Box + 4-LUT inverse MixColumns,
+    4,096 bits per launch): decrypt(encrypt(x)) == x for every block, and the ciphertexts fed in are AES ciphertexts"""
+    import torch
+
+    c = opt.client
+    key = c.key
+    rk = opt_server.aes_key_expansion(c.encrypt_u128(key))
+    n = 32
+    pts = [(IV + 0x9E3779B97F4A7C15 * i) & ((1 << 128) - 1) for i in range(n)]
+    states = np.stack([c.encrypt_u128(v) for v in pts])
+    d_rk = torch.from_numpy(rk.view(np.int64)).cuda()
+    d_st = torch.from_numpy(states.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    opt_server.aes_encrypt(d_rk, d_st)
+    opt_server.synchronize()
+    mid = d_st.cpu().numpy().view(np.uint64)
+    for i in range(n):
+        assert c.decrypt_u128(mid[i]) == aes_clear.aes128_encrypt_block(key, pts[i]), "block %d" % i
+    opt_server.aes_decrypt(d_rk, d_st)
+    opt_server.synchronize()
+    out = d_st.cpu().numpy().view(np.uint64)
+    for i in range(n):
+        assert c.decrypt_u128(out[i]) == pts[i], "block %d" % i
+    bits, ph = c.decrypt_bits(out, return_phase=True)
+    err = (ph - (bits.astype(np.uint64) << np.uint64(63))).astype(np.int64)
+    assert np.abs(err).max() < 1 << 59
+
+
 def test_ctr_counter_add_param_opt(opt, opt_server):
     c = opt.client
     st = np.stack([c.encrypt_u128(IV)] * 2)

@@ -36,9 +36,12 @@ def test_k1_keyswitch(which, m, request):
     assert np.array_equal(out, kit.oracle.keyswitch(x))
 
 
-@pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 8), ("toy", 21), ("toy", 530), ("opt", 1), ("opt", 7), ("opt", 520)])
+@pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 8), ("toy", 21), ("toy", 300), ("toy", 530),
+                                     ("opt", 1), ("opt", 7), ("opt", 300), ("opt", 520)])
 def test_k2_blind_rotation(which, m, request):
-    # m <= 512 runs the one-ciphertext-per-workgroup latency form, larger batches 3 (8 for the toy set) per workgroup
+    # every launch form of engine.hip::launch_cbs_pbs: m <= 256 the one-ciphertext-per-512-thread-workgroup latency kernel;
+    # 257..512 at k=4 the throughput kernel of kern_extprod.h with one ciphertext per workgroup; larger batches
+    # kern_blindrot16.h with 3 (k=4) or 8 (k=1) ciphertexts per workgroup
     kit = request.getfixturevalue(which)
     p, E = kit.params, kit.engine()
     x, bits = _inputs(kit, m, 20 + m)
@@ -85,6 +88,33 @@ def test_k5_vertical_packing(which, request):
     out = np.zeros_like(want)
     E.vertical_packing_batch(np.ascontiguousarray(ggsw_f), 2, 8, luts, 4, False, out)
     assert np.array_equal(out, want)
+
+
+def test_k5_vertical_packing_9bit_per_input_luts_param_opt(opt):
+    """the add_scalar shape at the reference's parameter set: 9 input bits, 2 LUTs that differ per input (server.rs:216-252);
+    exercises the 9-iteration instance of the vertical-packing kernel and the per-input LUT indexing"""
+    p, E, c, O = opt.params, opt.engine(), opt.client, opt.oracle
+    rng = np.random.default_rng(95)
+    n = 2
+    bits = rng.integers(0, 2, (n, 9)).astype(np.uint8)
+    x = c.encrypt_bits(bits)
+    from tfhe_aes_amd.server import gen_lut
+    adds = (0x7F, 0xF3)
+    luts = np.stack([np.stack([gen_lut(2, 1, 512, 9, lambda v, a=a: ((v & 0xFF) + (v >> 8) + a) % 256),
+                               gen_lut(2, 1, 512, 9, lambda v, a=a: 1 if (v & 0xFF) + (v >> 8) + a > 255 else 0)]) for a in adds])
+    want, dbg = O.wopbs_batch(x, luts, lut_per_input=True, debug=True)
+    out = np.zeros_like(want)
+    E.wopbs_batch(x, n, 9, luts, 2, True, out)                         # whole pipeline, bit-exact
+    assert np.array_equal(out, want)
+    ggsw_f = orc.polys_to_fourier(dbg["ggsw"].reshape(n, 9, -1, 512))
+    out2 = np.zeros_like(want)
+    E.vertical_packing_batch(np.ascontiguousarray(ggsw_f), n, 9, luts, 2, True, out2)   # K5 alone on the oracle's GGSWs
+    assert np.array_equal(out2, want)
+    dec = c.decrypt_bits(out)
+    for i, a in enumerate(adds):
+        v = int(sum(int(bits[i, j]) << j for j in range(9)))
+        s_ = (v & 0xFF) + (v >> 8) + a
+        assert int(sum(int(dec[i, 0, j]) << j for j in range(8))) == s_ % 256 and int(dec[i, 1, 0]) == (1 if s_ > 255 else 0)
 
 
 def test_zero_sized_batches_are_noops(toy):

@@ -67,5 +67,17 @@ def build_client(force: bool = False) -> Path:
     return CLIENT_SO
 
 
+def engine_source_hash() -> str:
+    """sha256 over the engine's sources (csrc/*.hip, csrc/*.h, include/fheaes.h): stamps measurements (profiles/*.json)
+    so that a counter summary is only ever attached to a run of the same kernels"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(ENGINE_SOURCES + ENGINE_HEADERS):
+        h.update(Path(f).name.encode())
+        h.update(Path(f).read_bytes())
+    return h.hexdigest()
+
+
 def build_all(force: bool = False):
     return build_engine(force), build_client(force)

@@ -11,6 +11,7 @@ Array conventions (see include/fheaes.h):
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -96,15 +97,24 @@ def bytes_to_u128(b) -> int:
 
 
 class Client:
-    """``Client::new`` (client.rs:70): generates the secret and evaluation keys from ``seed``."""
+    """``Client::new`` (client.rs:70): generates the secret and evaluation keys.
+
+    ``seed=None`` (the default, the counterpart of the reference's OS-seeded generators, client.rs:106-107): the key
+    seed and the seed of every encryption call are drawn from ``os.urandom``.  An explicit integer ``seed`` is the
+    TEST-ONLY deterministic mode (golden vectors, parity tests, synthetic bench data): keys derive from it and
+    encryption call i uses ``seed + 0x1000 * i`` -- two processes with the same seed then reuse masks and noise,
+    which is exactly what reproducible fixtures need and what real use must never do.  Either way the generator
+    is xoshiro256** (csrc/client.c), not a CSPRNG: this Client makes synthetic inputs for the engine, it is not a
+    hardened replacement of tfhe-rs key generation."""
 
     def __init__(self, number_of_outputs: int = 1, iv: int = 0, key: int = 0,
-                 params: WopbsParameters = PARAM_OPT, seed: int = 0xAE50001):
+                 params: WopbsParameters = PARAM_OPT, seed: int | None = None):
         self.params = params
         self.number_of_outputs = number_of_outputs
         self.iv = iv
         self.key = key
-        self.seed = seed
+        self.deterministic = seed is not None
+        self.seed = int(seed) & (2 ** 64 - 1) if seed is not None else int.from_bytes(os.urandom(8), "little")
         self._enc_counter = 0
         lib = _load()
         self._c = params.c_struct()
@@ -135,7 +145,8 @@ class Client:
         bits = np.ascontiguousarray(bits, dtype=np.uint8)
         out = np.empty(bits.shape + (self.params.big1,), dtype=np.uint64)
         self._enc_counter += 1
-        _load().fheaes_client_encrypt_bits(ctypes.byref(self._c), self.seed + 0x1000 * self._enc_counter, _u8(self.glwe_sk),
+        enc_seed = (self.seed + 0x1000 * self._enc_counter) & (2 ** 64 - 1) if self.deterministic else int.from_bytes(os.urandom(8), "little")
+        _load().fheaes_client_encrypt_bits(ctypes.byref(self._c), enc_seed, _u8(self.glwe_sk),
                                            self.params.glwe_noise_std, _u8(bits), bits.size, _u64(out))
         return out
 

@@ -201,6 +201,11 @@ struct fheaes_ctx {
     int lutset_n[LUTSET_COUNT] = {};
     // workspace
     DevBuf ws_small, ws_pbs, ws_ggsw, ws_ggswf, ws_vp, ws_tmp_a, ws_tmp_b, ws_luts, ws_misc, ws_digits, ws_park;
+    DevBuf stage[4];                     // host-memspace calls stage their arguments here (grow-only, reused)
+    // pinned host staging for the counter bytes of add_scalar; `pin_ev` marks the last copy out of it
+    uint8_t *pin = nullptr;
+    size_t pin_bytes = 0;
+    hipEvent_t pin_ev = nullptr;
     // profiling
     bool prof = false;
     struct Pending { hipEvent_t a, b; int stage; };
@@ -557,21 +562,18 @@ int wopbs_dev(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t n_inputs, uint32_t
     return FHEAES_OK;
 }
 
-// stage host arrays through device temporaries
+// Host-memspace calls: arguments are staged through context-owned device buffers (grown on demand, reused by later
+// calls -- the per-byte `sbox` call pattern of the reference's Rust side must not pay a hipMalloc/hipFree each time).
 struct Staged {
     fheaes_ctx *c;
-    std::vector<void *> bufs;
+    int used = 0;
     explicit Staged(fheaes_ctx *ctx) : c(ctx) {}
-    ~Staged()
-    {
-        (void)hipStreamSynchronize(c->stream);
-        for (void *b : bufs) (void)hipFree(b);
-    }
+    ~Staged() { (void)hipStreamSynchronize(c->stream); }      // host pointers are borrowed for the duration of the call only
     int alloc(void **out, size_t bytes)
     {
-        hipError_t e = hipMalloc(out, bytes ? bytes : 8);
-        if (e != hipSuccess) return c->fail(FHEAES_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
-        bufs.push_back(*out);
+        if (used >= 4) return c->fail(FHEAES_ERR_INVALID, "internal: too many staged arguments");
+        TRY(ensure(c, c->stage[used], bytes ? bytes : 8));
+        *out = c->stage[used++].p;
         return FHEAES_OK;
     }
     int in(const void *host, size_t bytes, void **dev)
@@ -681,6 +683,9 @@ void fheaes_destroy(fheaes_ctx *c)
                     c->ws_small.p, c->ws_pbs.p, c->ws_ggsw.p, c->ws_ggswf.p, c->ws_vp.p, c->ws_tmp_a.p, c->ws_tmp_b.p, c->ws_luts.p, c->ws_misc.p,
                     c->ws_park.p};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (auto &b : c->stage) if (b.p) (void)hipFree(b.p);
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pin_ev) (void)hipEventDestroy(c->pin_ev);
     for (int s = 0; s < LUTSET_COUNT; ++s) if (c->lutset_d[s]) (void)hipFree(c->lutset_d[s]);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -745,9 +750,11 @@ int fheaes_upload_keys(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, 
     void *tmp = nullptr;
     const size_t tmp_words = std::max(std::max(kw, bw), pw);
     if (memspace != FHEAES_DEVICE) HIP_TRY(c, hipMalloc(&tmp, tmp_words * 8));
+    hipError_t copy_err = hipSuccess;
     auto staged = [&](const uint64_t *src, size_t words) -> const uint64_t * {
         if (memspace == FHEAES_DEVICE) return src;
-        (void)hipMemcpyAsync(tmp, src, words * 8, hipMemcpyHostToDevice, c->stream);
+        hipError_t ce = hipMemcpyAsync(tmp, src, words * 8, hipMemcpyHostToDevice, c->stream);
+        if (ce != hipSuccess && copy_err == hipSuccess) copy_err = ce;
         return (const uint64_t *)tmp;
     };
     int rc = FHEAES_OK;
@@ -774,6 +781,7 @@ int fheaes_upload_keys(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, 
     hipError_t e = hipStreamSynchronize(c->stream);
     if (tmp) (void)hipFree(tmp);
     if (rc != FHEAES_OK) return rc;
+    if (copy_err != hipSuccess) return c->fail(FHEAES_ERR_DEVICE, "key upload (host -> device copy): %s", hipGetErrorString(copy_err));
     if (e != hipSuccess) return c->fail(FHEAES_ERR_DEVICE, "key upload: %s", hipGetErrorString(e));
     HIP_TRY(c, hipGetLastError());
     if (c->prof) prof_flush(c);
@@ -1033,8 +1041,18 @@ int fheaes_aes_key_expansion(fheaes_ctx *c, const uint64_t *key, uint64_t *round
 static int add_scalar_dev(fheaes_ctx *c, uint64_t *state, uint64_t n_blocks, const uint64_t *counters)
 {
     const uint32_t lw = c->big1;
-    // counter bytes, MSB first (server.rs:174-178): addend[byte][blk]
-    std::vector<uint8_t> add(16 * n_blocks);
+    // counter bytes, MSB first (server.rs:174-178): addend[byte][blk], staged through a context-owned pinned buffer so
+    // that the call only ENQUEUES (fheaes.h: FHEAES_DEVICE calls are not synchronised).  The only wait is for the copy
+    // out of that buffer that an earlier add_scalar enqueued.
+    const size_t add_bytes = 16 * n_blocks;
+    if (c->pin_ev) HIP_TRY(c, hipEventSynchronize(c->pin_ev));
+    else HIP_TRY(c, hipEventCreateWithFlags(&c->pin_ev, hipEventDisableTiming));
+    if (c->pin_bytes < add_bytes) {
+        if (c->pin) { HIP_TRY(c, hipHostFree(c->pin)); c->pin = nullptr; c->pin_bytes = 0; }
+        HIP_TRY(c, hipHostMalloc((void **)&c->pin, add_bytes, hipHostMallocDefault));
+        c->pin_bytes = add_bytes;
+    }
+    uint8_t *add = c->pin;
     for (uint64_t b = 0; b < n_blocks; ++b) {
         uint64_t hi = counters[2 * b], lo = counters[2 * b + 1];
         for (int j = 0; j < 8; ++j) { add[(15 - j) * n_blocks + b] = (uint8_t)(lo >> (8 * j)); add[(7 - j) * n_blocks + b] = (uint8_t)(hi >> (8 * j)); }
@@ -1042,8 +1060,8 @@ static int add_scalar_dev(fheaes_ctx *c, uint64_t *state, uint64_t n_blocks, con
     TRY(ensure(c, c->ws_misc, 16 * n_blocks + n_blocks * lw * 8 + 64));
     uint8_t *add_d = (uint8_t *)c->ws_misc.p;
     uint64_t *carry = (uint64_t *)((uint8_t *)c->ws_misc.p + ((16 * n_blocks + 63) / 64) * 64);
-    HIP_TRY(c, hipMemcpyAsync(add_d, add.data(), add.size(), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));   // `add` is a local
+    HIP_TRY(c, hipMemcpyAsync(add_d, add, add_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(c->pin_ev, c->stream));
     TRY(ensure(c, c->ws_tmp_a, n_blocks * 9ull * lw * 8));
     TRY(ensure(c, c->ws_tmp_b, n_blocks * 2ull * 9 * lw * 8));
     TRY(ensure(c, c->ws_luts, n_blocks * 2ull * 9 * FHE_N * 8));

@@ -28,6 +28,18 @@
 #endif
 #define BR16_PARK_WORDS_PER_WG (16 * EP_THREADS * 2 * 2)   /* 16 chunks of 32 bytes per thread: lo[a], hi[a] pairs */
 
+// One 16-byte key element through a raw buffer load: the address is (buffer base, scalar) + (row offset, scalar) +
+// (16 * point, the only vector part), so a key fetch costs no vector address arithmetic at all.
+typedef unsigned br16_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double2 br16_key_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_bytes, unsigned row_bytes)
+{
+    br16_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, row_bytes, 0);
+    double2 d;
+    d.x = __longlong_as_double((long long)(((unsigned long long)v[1] << 32) | v[0]));
+    d.y = __longlong_as_double((long long)(((unsigned long long)v[3] << 32) | v[2]));
+    return d;
+}
+
 __device__ __forceinline__ int br16_opaque_tid()
 {
     int t = threadIdx.x;
@@ -54,9 +66,11 @@ template <int K1, int LEVELS, int BASE_LOG, int R>
 __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const ExtProdArgs A)
 {
     static_assert(R * K1 <= EP_GROUPS, "too many polynomials for 16 lane groups");
-    __shared__ __attribute__((aligned(16))) double lds[EP_LDS_DOUBLES];
-    double2 *psi = reinterpret_cast<double2 *>(lds + EP_GROUPS * GROUP_TILE_DOUBLES);
+    // twiddle tables first: their addresses then fit the 16-bit offset field of the LDS instructions
+    __shared__ __attribute__((aligned(16))) double lds_all[EP_LDS_DOUBLES];
+    double2 *psi = reinterpret_cast<double2 *>(lds_all);
     double2 *tw = psi + FHE_H;
+    double *lds = lds_all + 2 * 2 * FHE_H;                        // the 16 group tiles
 
     const int tid = threadIdx.x;
     const int g = tid >> 4, b = tid & 15;
@@ -91,7 +105,9 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
     ulonglong2 *park = reinterpret_cast<ulonglong2 *>(A.park) + (size_t)blockIdx.x * 16 * EP_THREADS;   // wave-uniform
     __syncthreads();   // tables visible
 
-    constexpr size_t GGSW_STRIDE = (size_t)LEVELS * K1 * K1 * FHE_H;
+    constexpr unsigned GGSW_BYTES = LEVELS * K1 * K1 * FHE_H * 16;   // one GGSW of the Fourier BSK
+    // the whole Fourier BSK as one raw buffer (< 2^31 bytes for every supported parameter set: checked by the launcher)
+    const __amdgpu_buffer_rsrc_t bsk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(A.ggsw), 0, (int)(A.iters * GGSW_BYTES), 0x00020000);
     uint64_t a_next = lwe[0];
 
 #ifdef EP_STAMPS
@@ -102,7 +118,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
     for (uint32_t it = 0; it < A.iters; ++it) {
         const int t = mod_switch_1024(a_next);
         a_next = lwe[it + 1];                                    // one iteration ahead (the last one reads the body: unused)
-        const double2 *G = A.ggsw + (size_t)it * GGSW_STRIDE;    // wave-uniform
+        const unsigned g_bytes = it * GGSW_BYTES;                // wave-uniform byte offset of this iteration's GGSW
 
         // ---- accumulator -> tile and parking slab; d = acc * X^t - acc; first (least significant) digit -----------
         uint32_t st_lo[16], st_hi[16];
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
                 *reinterpret_cast<double2 *>(tile + 2 * (bq_ + 16 * k2)) = v;
             }
             __builtin_amdgcn_sched_barrier(0);
-            const double2 *Gl = G + (size_t)l * K1 * K1 * FHE_H;   // wave-uniform row pointers; the lane adds 16 * point
+            const unsigned gl_bytes = g_bytes + (unsigned)l * (K1 * K1 * FHE_H * 16);   // scalar; the lane adds 16 * point
             double2 bm[K1][K1];
 #pragma unroll
             for (int p = 0; p < K1; ++p)
@@ -196,7 +212,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
 #ifdef BR16_ABL_NOLOAD
                 for (int c = 0; c < K1; ++c) bm[p][c] = make_double2((double)(tq + c + p), (double)(tq - c));
 #else
-                for (int c = 0; c < K1; ++c) bm[p][c] = (Gl + (p * K1 + c) * FHE_H)[(unsigned)tq];
+                for (int c = 0; c < K1; ++c) bm[p][c] = br16_key_load(bsk_rsrc, (unsigned)tq * 16u, gl_bytes + (unsigned)(p * K1 + c) * (FHE_H * 16));
 #endif
             __builtin_amdgcn_sched_barrier(0);
             EP_STAMP(5);

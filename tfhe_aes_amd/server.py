@@ -45,7 +45,10 @@ def _to_space(arr: np.ndarray, ref):
         return np.ascontiguousarray(arr, dtype=np.uint64)
     import torch
 
-    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).view(np.int64)).to(ref.device)
+    dev = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint64).view(np.int64)).to(ref.device)
+    # the copy ran on torch's current stream; the engine reads `dev` on ITS stream: finish the copy first
+    torch.cuda.current_stream(ref.device).synchronize()
+    return dev
 
 
 class Server:
@@ -54,6 +57,9 @@ class Server:
     def __init__(self, keys: ServerKeys, device: int = 0, engine: _native.Engine | None = None):
         self.params: WopbsParameters = keys.params
         self.engine = engine or _native.Engine(keys.params, device)
+        # device temporaries this wrapper created for calls that are still in flight on the engine's stream; they must
+        # outlive the kernels that read them (torch's caching allocator would hand the block out again): freed in synchronize()
+        self._inflight = []
         self.engine.upload_keys(np.ascontiguousarray(keys.ksk), np.ascontiguousarray(keys.bsk), np.ascontiguousarray(keys.pfpksk))
 
     # ---- S-Box front end --------------------------------------------------------
@@ -75,6 +81,8 @@ class Server:
         lut_dev = _to_space(lut_arr, ct_in) if isinstance(lut_arr, np.ndarray) else lut_arr
         out = _empty_like(ct_in, (n, n_luts, bits, self.params.big1))
         self.engine.wopbs_batch(ct_in, n, bits, lut_dev, n_luts, per_input, out)
+        if not isinstance(ct_in, np.ndarray) and lut_dev is not luts:
+            self._inflight.append(lut_dev)            # device call: only enqueued, the LUT copy is still being read
         return out
 
     def sbox(self, ct_in, inv: bool):
@@ -123,3 +131,4 @@ class Server:
 
     def synchronize(self):
         self.engine.synchronize()
+        self._inflight.clear()

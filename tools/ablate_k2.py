@@ -68,7 +68,7 @@ def main():
     out = Path("gpurun_out/abl")
     out.mkdir(parents=True, exist_ok=True)
     p = PARAM_OPT
-    c = Client(1, 1, 2, params=p)
+    c = Client(1, 1, 2, params=p, seed=0xAE50001)
     keys = c.server_keys()
     rng = np.random.default_rng(0)
     small = rng.integers(0, 1 << 64, (M, p.n + 1), dtype=np.uint64)

@@ -17,7 +17,7 @@ VARIANTS = {"pf2": ["-DBL_PREFETCH=2"], "pf3": ["-DBL_PREFETCH=3"], "pf4": ["-DB
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(VARIANTS)
 out = Path("gpurun_out/abl"); out.mkdir(parents=True, exist_ok=True)
 p = PARAM_OPT
-c = Client(1, 1, 2, params=p)
+c = Client(1, 1, 2, params=p, seed=0xAE50001)
 keys = c.server_keys()
 x = c.encrypt_bytes(list(range(16)))
 for name in names:

@@ -21,7 +21,7 @@ def check(name, a, b):
 def run(p, m_bits, full_aes):
     print("== %s" % p.name, flush=True)
     t = time.time()
-    c = Client(1, 0x6bc1bee22e409f96e93d7e117393172a, 0x2b7e151628aed2a6abf7158809cf4f3c, params=p)
+    c = Client(1, 0x6bc1bee22e409f96e93d7e117393172a, 0x2b7e151628aed2a6abf7158809cf4f3c, params=p, seed=0xAE50001)
     keys, st, ek = c.client_encrypt()
     print("  keygen %.1fs" % (time.time() - t), flush=True)
     O = orc.Oracle(p, keys.ksk, keys.bsk, keys.pfpksk)

@@ -12,7 +12,7 @@ from tfhe_aes_amd import PARAM_OPT, _native  # noqa: E402
 from tfhe_aes_amd.client import Client  # noqa: E402
 
 p = PARAM_OPT
-c = Client(1, 0xF0F1F2F3F4F5F6F7F8F9FAFBFCFDFEFF, 0x2B7E151628AED2A6ABF7158809CF4F3C, params=p)
+c = Client(1, 0xF0F1F2F3F4F5F6F7F8F9FAFBFCFDFEFF, 0x2B7E151628AED2A6ABF7158809CF4F3C, params=p, seed=0xAE50001)
 keys, st, ek = c.client_encrypt()
 E = _native.Engine(p)
 E.upload_keys(keys.ksk, keys.bsk, keys.pfpksk)

@@ -15,7 +15,7 @@ from tfhe_aes_amd.client import Client  # noqa: E402
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 p = PARAM_OPT
-c = Client(1, 1, 2, params=p)
+c = Client(1, 1, 2, params=p, seed=0xAE50001)
 keys = c.server_keys()
 E = _native.Engine(p)
 E.upload_keys(keys.ksk, keys.bsk, keys.pfpksk)

@@ -39,5 +39,9 @@ if "TCC_HIT_sum" in per:
 if "SQ_WAVE_CYCLES" in per:
     w = per["SQ_WAVE_CYCLES"]
     out["wave_time_split"] = {"active": per["SQ_ACTIVE_INST_ANY"] / w, "wait_inst": per["SQ_WAIT_INST_ANY"] / w, "wait_any": per["SQ_WAIT_ANY"] / w}
+sys.path.insert(0, ".")
+from tfhe_aes_amd import _build  # noqa: E402
+
+out["engine_src_sha256"] = _build.engine_source_hash()       # bench.py attaches `traffic` only to runs of the same sources
 json.dump(out, open(prefix + ".json", "w"), indent=1)
 print(json.dumps(out, indent=1))
