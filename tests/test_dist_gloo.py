@@ -37,8 +37,8 @@ def _worker(rank, world, port, q):
 
     from oracle import oracle as orc
     from tfhe_aes_amd import PARAM_TOY, aes_clear
-    from tfhe_aes_amd.client import Client, ServerKeys
-    from tfhe_aes_amd.dist import broadcast_keys, broadcast_tensor
+    from tfhe_aes_amd.client import Client, SeededServerKeys, ServerKeys
+    from tfhe_aes_amd.dist import broadcast_keys, broadcast_keys_seeded, broadcast_tensor
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -49,6 +49,10 @@ def _worker(rank, world, port, q):
         dev = torch.device("cpu")
         tk = broadcast_keys(p, keys, dev, src=0)
         got = ServerKeys(p, *[t.numpy().view(np.uint64) for t in tk])
+        # the compressed form bench.py ships: (mask seed, bodies); expanding it gives the very same keys on every rank
+        mseed, tb = broadcast_keys_seeded(p, keys.compress() if rank == 0 else None, dev, src=0)
+        exp = SeededServerKeys(p, mseed, *[t.numpy().view(np.uint64) for t in tb]).expand()
+        assert np.array_equal(exp.ksk, got.ksk) and np.array_equal(exp.bsk, got.bsk) and np.array_equal(exp.pfpksk, got.pfpksk)
         O = orc.Oracle(p, got.ksk, got.bsk, got.pfpksk)
         rk = torch.empty((11, 16, 8, p.big1), dtype=torch.int64)
         if rank == 0:

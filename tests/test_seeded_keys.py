@@ -1,0 +1,97 @@
+"""Seeded evaluation keys (first slice): keys travel as (public mask seed, bodies) and every mask word
+is regenerated -- on the host by SeededServerKeys.expand(), on the GPU by fheaes_upload_keys_seeded."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tfhe_aes_amd import client as cl
+from tfhe_aes_amd.client import SeededServerKeys, ServerKeys
+
+
+def test_mask_stream_numpy_matches_c():
+    lib = cl._load()
+    w = cl.mask_words(0x1234567890ABCDEF, cl.MASK_TAG_BSK, 7, 40)
+    for q, j in ((0, 0), (3, 17), (6, 39)):
+        assert int(w[q, j]) == lib.fheaes_client_mask_word(0x1234567890ABCDEF, cl.MASK_TAG_BSK, q, j)
+
+
+def test_compress_expand_roundtrip_and_sizes(toy, tmp_path):
+    p, keys = toy.params, toy.keys
+    sk = keys.compress()
+    assert sk.ksk_body.shape == (p.big, p.ks_level) and sk.bsk_body.shape == (p.n, p.pbs_level, p.k + 1, p.N)
+    assert sk.pfpksk_body.shape == (p.k + 1, p.big1, p.pfks_level, p.N)
+    full = sk.expand()
+    assert np.array_equal(full.ksk, keys.ksk) and np.array_equal(full.bsk, keys.bsk) and np.array_equal(full.pfpksk, keys.pfpksk)
+    # file round trip (npz of uint64 arrays, no pickle)
+    sk.save(tmp_path / "k.npz")
+    back = SeededServerKeys.load(tmp_path / "k.npz", p)
+    assert back.mask_seed == sk.mask_seed and np.array_equal(back.bsk_body, sk.bsk_body)
+    with pytest.raises(ValueError):
+        ServerKeys(p, keys.ksk, keys.bsk, keys.pfpksk).compress()         # foreign keys carry no mask seed
+
+
+def test_compression_ratio_param_opt():
+    from tfhe_aes_amd import PARAM_OPT as p
+
+    full = 8 * (p.ksk_words + p.bsk_words + p.pfpksk_words)
+    body = 8 * (p.big * p.ks_level + p.n * p.pbs_level * (p.k + 1) * p.N + (p.k + 1) * p.big1 * p.pfks_level * p.N)
+    assert full == 1_037_844_480 and body == 194_494_464                   # 5.3x fewer bytes over PCIe / xGMI
+
+
+def test_bsk_rows_keep_the_message_out_of_the_masks(toy):
+    """GGSW row (l, r) carries s_i * g_l on component r through its BODY (-g_l S_r(X), or +g_l for r = k): the phases are
+    those of a GGSW of s_i and no mask word depends on a secret"""
+    p, c = toy.params, toy.client
+    bsk = toy.keys.bsk.reshape(p.n, p.pbs_level, p.k + 1, (p.k + 1) * p.N)
+    S = c.glwe_sk.reshape(p.k, p.N).astype(np.int64)
+    for i in (0, p.n - 1):
+        ph = c.glwe_phase(bsk[i])                                          # [L][k+1][N]
+        for l in range(p.pbs_level):
+            g = 1 << (64 - p.pbs_base_log * (l + 1))
+            for r in range(p.k + 1):
+                want = np.zeros(p.N, dtype=np.int64)
+                if c.lwe_sk[i]:
+                    if r == p.k:
+                        want[0] = g
+                    else:
+                        want = -g * S[r]
+                err = (ph[l, r].astype(np.int64) - want.astype(np.int64))
+                assert np.abs(err).max() < 1 << 30
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["toy", "opt"])
+def test_seeded_upload_equals_full_upload(which, request):
+    """device keys built from (mask_seed, bodies) are the device keys of the uncompressed upload: K1, K2's Fourier BSK and
+    K3 give array_equal outputs"""
+    from tfhe_aes_amd import _native
+
+    kit = request.getfixturevalue(which)
+    p = kit.params
+    sk = kit.keys.compress()
+    E_full = kit.engine()
+    E = _native.Engine(p, device=0)
+    E.upload_keys_seeded(sk.mask_seed, sk.ksk_body, sk.bsk_body, sk.pfpksk_body)
+    for i in (0, p.n // 2, p.n - 1):
+        assert np.array_equal(E.read_bsk_fourier(i).view(np.uint64), E_full.read_bsk_fourier(i).view(np.uint64))
+    rng = np.random.default_rng(11)
+    m = 19
+    x = rng.integers(0, 1 << 64, (m, p.big1), dtype=np.uint64)
+    a, b = np.zeros((m, p.n + 1), dtype=np.uint64), np.zeros((m, p.n + 1), dtype=np.uint64)
+    E.keyswitch_batch(x, a, m)
+    E_full.keyswitch_batch(x, b, m)
+    assert np.array_equal(a, b) and np.array_equal(a, kit.oracle.keyswitch(x))
+    g1 = np.zeros((m, p.k + 1, (p.k + 1) * 512), dtype=np.uint64)
+    g2 = np.zeros_like(g1)
+    E.pfpks_batch(x, g1, m)
+    E_full.pfpks_batch(x, g2, m)
+    assert np.array_equal(g1, g2)
+    bits = rng.integers(0, 2, 5).astype(np.uint8)
+    ct = kit.client.encrypt_bits(bits)
+    small = kit.oracle.keyswitch(ct)
+    o1, o2 = np.zeros((5, p.big1), dtype=np.uint64), np.zeros((5, p.big1), dtype=np.uint64)
+    E.cbs_pbs_batch(small, o1, 5)
+    E_full.cbs_pbs_batch(small, o2, 5)
+    assert np.array_equal(o1, o2)
+    E.close()

@@ -29,6 +29,8 @@ SIGNATURES = {
     "fheaes_last_error": (_c.c_char_p, [_ctx]),
     "fheaes_key_words": (_c.c_size_t, [_ctx, _c.c_int]),
     "fheaes_upload_keys": (_c.c_int, [_ctx, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int]),
+    "fheaes_key_body_words": (_c.c_size_t, [_ctx, _c.c_int]),
+    "fheaes_upload_keys_seeded": (_c.c_int, [_ctx, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int]),
     "fheaes_set_stream": (_c.c_int, [_ctx, _c.c_void_p]),
     "fheaes_synchronize": (_c.c_int, [_ctx]),
     "fheaes_reserve": (_c.c_int, [_ctx, _c.c_uint64]),
@@ -151,6 +153,16 @@ class Engine:
             if n != self.key_words(which):
                 raise ValueError("key %d has %d words, expected %d" % (which, n, self.key_words(which)))
         self._check(self._lib.fheaes_upload_keys(self._h, _ptr(ksk)[0], _ptr(bsk)[0], _ptr(pfpksk)[0], sp))
+
+    def upload_keys_seeded(self, mask_seed: int, ksk_body, bsk_body, pfpksk_body):
+        """keys as (public mask seed, bodies): masks are regenerated on the GPU (include/fheaes.h)"""
+        sp = self._space(ksk_body, bsk_body, pfpksk_body)
+        for which, a in enumerate((ksk_body, bsk_body, pfpksk_body)):
+            n = a.size if isinstance(a, np.ndarray) else a.numel()
+            if n != self._lib.fheaes_key_body_words(self._h, which):
+                raise ValueError("key body %d has %d words, expected %d" % (which, n, self._lib.fheaes_key_body_words(self._h, which)))
+        self._check(self._lib.fheaes_upload_keys_seeded(self._h, int(mask_seed) & (2 ** 64 - 1), _ptr(ksk_body)[0], _ptr(bsk_body)[0],
+                                                        _ptr(pfpksk_body)[0], sp))
 
     def set_stream(self, stream_handle: int | None):
         self._check(self._lib.fheaes_set_stream(self._h, stream_handle))

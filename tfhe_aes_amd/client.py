@@ -31,9 +31,11 @@ def _load():
         u64p = ctypes.POINTER(ctypes.c_uint64)
         pp = ctypes.POINTER(CParams)
         lib.fheaes_client_gen_secret_keys.argtypes = [pp, ctypes.c_uint64, u8p, u8p]
-        lib.fheaes_client_gen_ksk.argtypes = [pp, ctypes.c_uint64, u8p, u8p, ctypes.c_double, u64p]
-        lib.fheaes_client_gen_bsk.argtypes = [pp, ctypes.c_uint64, u8p, u8p, ctypes.c_double, u64p]
-        lib.fheaes_client_gen_pfpksk.argtypes = [pp, ctypes.c_uint64, u8p, ctypes.c_double, u64p]
+        lib.fheaes_client_gen_ksk.argtypes = [pp, ctypes.c_uint64, ctypes.c_uint64, u8p, u8p, ctypes.c_double, u64p]
+        lib.fheaes_client_gen_bsk.argtypes = [pp, ctypes.c_uint64, ctypes.c_uint64, u8p, u8p, ctypes.c_double, u64p]
+        lib.fheaes_client_gen_pfpksk.argtypes = [pp, ctypes.c_uint64, ctypes.c_uint64, u8p, ctypes.c_double, u64p]
+        lib.fheaes_client_mask_word.argtypes = [ctypes.c_uint64] * 4
+        lib.fheaes_client_mask_word.restype = ctypes.c_uint64
         lib.fheaes_client_encrypt_bits.argtypes = [pp, ctypes.c_uint64, u8p, ctypes.c_double, u8p, ctypes.c_uint64, u64p]
         lib.fheaes_client_decrypt_bits.argtypes = [pp, u8p, u64p, ctypes.c_uint64, u8p, u64p]
         lib.fheaes_client_phase_small.argtypes = [pp, u8p, u64p, ctypes.c_uint64, u64p]
@@ -54,6 +56,81 @@ def _u64(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
 
 
+MASK_TAG_KSK, MASK_TAG_BSK, MASK_TAG_PFPKSK = 3, 4, 5          # csrc/client.c, csrc/engine.hip
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    """splitmix64 finaliser on numpy uint64 arrays (wrapping arithmetic)"""
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def mask_words(mask_seed: int, tag: int, n_cts: int, words_per_ct: int) -> np.ndarray:
+    """The public mask stream of csrc/client.c in numpy: [n_cts][words_per_ct] uint64.  Host-side twin of the
+    engine's expansion kernel (tests compare both with the masks inside the full keys)."""
+    with np.errstate(over="ignore"):
+        ct = np.arange(n_cts, dtype=np.uint64)
+        base = _mix64(np.uint64(mask_seed & _M64) ^ np.uint64((tag * 0xD6E8FEB86659FD93) & _M64) ^ (ct * np.uint64(0xA24BAED4963EE407)))
+        j = np.arange(1, words_per_ct + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        return _mix64(base[:, None] + j[None, :])
+
+
+@dataclass
+class SeededServerKeys:
+    """The evaluation keys as (public mask seed, bodies): every mask word is regenerated from ``mask_seed`` (on the GPU by
+    ``fheaes_upload_keys_seeded``, on the host by ``expand()``), so 0.19 GB travel instead of 1.04 GB at PARAM_OPT.
+    Bodies: KSK [kN][ks_level] words; BSK [n][pbs_level][k+1][N]; PFPKSK [k+1][kN+1][pfks_level][N]."""
+    params: WopbsParameters
+    mask_seed: int
+    ksk_body: np.ndarray
+    bsk_body: np.ndarray
+    pfpksk_body: np.ndarray
+
+    @property
+    def nbytes(self) -> int:
+        return 8 + self.ksk_body.nbytes + self.bsk_body.nbytes + self.pfpksk_body.nbytes
+
+    def expand(self) -> "ServerKeys":
+        p = self.params
+        k, N, n = p.k, p.N, p.n
+        ksk = np.empty((p.big * p.ks_level, n + 1), dtype=np.uint64)
+        ksk[:, :n] = mask_words(self.mask_seed, MASK_TAG_KSK, p.big * p.ks_level, n)
+        ksk[:, n] = self.ksk_body.reshape(-1)
+        nb = p.n * p.pbs_level * (k + 1)
+        bsk = np.empty((nb, (k + 1) * N), dtype=np.uint64)
+        bsk[:, :k * N] = mask_words(self.mask_seed, MASK_TAG_BSK, nb, k * N)
+        bsk[:, k * N:] = self.bsk_body.reshape(nb, N)
+        npf = (k + 1) * p.big1 * p.pfks_level
+        pf = np.empty((npf, (k + 1) * N), dtype=np.uint64)
+        pf[:, :k * N] = mask_words(self.mask_seed, MASK_TAG_PFPKSK, npf, k * N)
+        pf[:, k * N:] = self.pfpksk_body.reshape(npf, N)
+        return ServerKeys(p, ksk.reshape(-1), bsk.reshape(-1), pf.reshape(-1), mask_seed=self.mask_seed)
+
+    def save(self, path) -> None:
+        np.savez(path, shape=_param_shape(self.params), mask_seed=np.array([self.mask_seed], dtype=np.uint64),
+                 ksk_body=self.ksk_body, bsk_body=self.bsk_body, pfpksk_body=self.pfpksk_body)
+
+    @staticmethod
+    def load(path, params: WopbsParameters) -> "SeededServerKeys":
+        with np.load(path, allow_pickle=False) as z:
+            if list(map(int, z["shape"])) != list(map(int, _param_shape(params))):
+                raise ValueError("key file was generated for a different parameter set")
+            out = SeededServerKeys(params, int(z["mask_seed"][0]), z["ksk_body"].astype(np.uint64), z["bsk_body"].astype(np.uint64),
+                                   z["pfpksk_body"].astype(np.uint64))
+        k, N = params.k, params.N
+        want = (params.big * params.ks_level, params.n * params.pbs_level * (k + 1) * N, (k + 1) * params.big1 * params.pfks_level * N)
+        if (out.ksk_body.size, out.bsk_body.size, out.pfpksk_body.size) != want:
+            raise ValueError("key file has the wrong array sizes")
+        return out
+
+
+def _param_shape(p: WopbsParameters) -> np.ndarray:
+    return np.array([p.lwe_dimension, p.glwe_dimension, p.polynomial_size, p.pbs_base_log, p.pbs_level, p.ks_base_log,
+                     p.ks_level, p.pfks_base_log, p.pfks_level, p.cbs_base_log, p.cbs_level], dtype=np.uint32)
+
+
 @dataclass
 class ServerKeys:
     """What ``client_encrypt`` hands to ``Server::new`` (client.rs:143): the evaluation keys."""
@@ -62,14 +139,23 @@ class ServerKeys:
     ksk: np.ndarray      # [kN][ks_level][n+1]
     bsk: np.ndarray      # [n][pbs_level][k+1][k+1][N]   standard domain
     pfpksk: np.ndarray   # [k+1][kN+1][pfks_level][(k+1)N]
+    mask_seed: int | None = None   # set when the masks follow the public stream of csrc/client.c (keys made by Client)
+
+    def compress(self) -> "SeededServerKeys":
+        """(mask_seed, bodies): drops every mask word (they are a function of the public mask seed)"""
+        if self.mask_seed is None:
+            raise ValueError("these keys do not carry a mask seed (not generated by Client)")
+        p = self.params
+        k, N, n = p.k, p.N, p.n
+        ksk_b = np.ascontiguousarray(self.ksk.reshape(-1, n + 1)[:, n]).reshape(p.big, p.ks_level)
+        bsk_b = np.ascontiguousarray(self.bsk.reshape(-1, (k + 1) * N)[:, k * N:]).reshape(p.n, p.pbs_level, k + 1, N)
+        pf_b = np.ascontiguousarray(self.pfpksk.reshape(-1, (k + 1) * N)[:, k * N:]).reshape(k + 1, p.big1, p.pfks_level, N)
+        return SeededServerKeys(p, self.mask_seed, ksk_b, bsk_b, pf_b)
 
     # The reference never serialises anything (SURVEY.md section 5); these two helpers exist so that keys produced
     # elsewhere can be fed to the engine.  Plain .npz of uint64 arrays (no pickle), layouts as in include/fheaes.h.
     def save(self, path) -> None:
-        p = self.params
-        shape = np.array([p.lwe_dimension, p.glwe_dimension, p.polynomial_size, p.pbs_base_log, p.pbs_level, p.ks_base_log,
-                          p.ks_level, p.pfks_base_log, p.pfks_level, p.cbs_base_log, p.cbs_level], dtype=np.uint32)
-        np.savez(path, shape=shape, ksk=self.ksk, bsk=self.bsk, pfpksk=self.pfpksk)
+        np.savez(path, shape=_param_shape(self.params), ksk=self.ksk, bsk=self.bsk, pfpksk=self.pfpksk)
 
     @staticmethod
     def load(path, params: WopbsParameters) -> "ServerKeys":
@@ -115,6 +201,9 @@ class Client:
         self.key = key
         self.deterministic = seed is not None
         self.seed = int(seed) & (2 ** 64 - 1) if seed is not None else int.from_bytes(os.urandom(8), "little")
+        # PUBLIC seed of the evaluation keys' mask words (it travels with the compressed keys); independent of the
+        # secret seed unless the deterministic test mode derives both from one number
+        self.mask_seed = (self.seed * 0x9E3779B97F4A7C15 + 0xA5A5A5A5) & (2 ** 64 - 1) if seed is not None else int.from_bytes(os.urandom(8), "little")
         self._enc_counter = 0
         lib = _load()
         self._c = params.c_struct()
@@ -131,12 +220,12 @@ class Client:
             ksk = np.empty(p.ksk_words, dtype=np.uint64)
             bsk = np.empty(p.bsk_words, dtype=np.uint64)
             pf = np.empty(p.pfpksk_words, dtype=np.uint64)
-            lib.fheaes_client_gen_ksk(ctypes.byref(self._c), self.seed, _u8(self.lwe_sk), _u8(self.glwe_sk),
+            lib.fheaes_client_gen_ksk(ctypes.byref(self._c), self.seed, self.mask_seed, _u8(self.lwe_sk), _u8(self.glwe_sk),
                                       p.lwe_noise_std, _u64(ksk))
-            lib.fheaes_client_gen_bsk(ctypes.byref(self._c), self.seed, _u8(self.lwe_sk), _u8(self.glwe_sk),
+            lib.fheaes_client_gen_bsk(ctypes.byref(self._c), self.seed, self.mask_seed, _u8(self.lwe_sk), _u8(self.glwe_sk),
                                       p.glwe_noise_std, _u64(bsk))
-            lib.fheaes_client_gen_pfpksk(ctypes.byref(self._c), self.seed, _u8(self.glwe_sk), p.pfks_noise_std, _u64(pf))
-            self._server_keys = ServerKeys(p, ksk, bsk, pf)
+            lib.fheaes_client_gen_pfpksk(ctypes.byref(self._c), self.seed, self.mask_seed, _u8(self.glwe_sk), p.pfks_noise_std, _u64(pf))
+            self._server_keys = ServerKeys(p, ksk, bsk, pf, mask_seed=self.mask_seed)
         return self._server_keys
 
     # -- encryption -----------------------------------------------------------

@@ -11,14 +11,20 @@
  * Key layouts (shared with include/fheaes.h; level index 0 = most significant level):
  *   small key  s  [n]  bits;  GLWE key S [k][N] bits;  big LWE key = S flattened (kN bits)
  *   KSK    [kN][ks_level][n+1]              row (i,l) = LWE_s ( S_flat[i] * 2^(64-b(l+1)) )
- *   BSK    [n][pbs_level][k+1][k+1][N]      GGSW(s_i): row (l,r) = GLWE_S(0) + s_i*2^(64-b(l+1)) on poly r
+ *   BSK    [n][pbs_level][k+1][k+1][N]      GGSW(s_i): row (l,r) = GLWE_S( s_i * f_r(2^(64-b(l+1))) ), f_r as below
  *   PFPKSK [k+1][kN+1][pfks_level][(k+1)N]  row (r,i,l) = GLWE_S( f_r(sigma_i * 2^(64-b(l+1))) ),
  *          sigma_i = S_flat[i] (i<kN), sigma_kN = -1;  f_r(x) = -x*S_r(X) (r<k), f_k(x) = x
  * 
  *
- * Randomness: xoshiro256** seeded per key row from (seed, tag, row) through splitmix64, so the
- * output does not depend on the thread count.  Gaussian noise by the Marsaglia polar method
- * with a series logarithm (only + - * / sqrt: no libm dependence, bit-reproducible).
+ * Randomness.  Two independent inputs:
+ *   seed       SECRET: secret keys and every noise sample (xoshiro256** seeded per key ciphertext from
+ *              (seed, tag, index) through splitmix64, so the output does not depend on the thread count;
+ *              Gaussian noise by the Marsaglia polar method with a series logarithm: + - * / sqrt only, no libm
+ *              dependence, bit-reproducible);
+ *   mask_seed  PUBLIC: every mask word of the evaluation keys.  Mask word j of key ciphertext q of key `tag` is the
+ *              j-th output of the splitmix64 sequence started at mix(mask_seed, tag, q) -- a counter-based stream with
+ *              random access, so the engine can regenerate all masks on the GPU from (mask_seed, bodies):
+ *              fheaes_upload_keys_seeded ships 0.19 GB instead of 1.04 GB (include/fheaes.h).
  * Synthetic-data quality, not a CSPRNG.
  */
 #include <stdint.h>
@@ -45,6 +51,23 @@ static void rng_seed(rng_t *r, uint64_t seed, uint64_t tag, uint64_t row)
     uint64_t x = seed ^ (tag * 0xD6E8FEB86659FD93ULL) ^ (row * 0xA24BAED4963EE407ULL);
     for (int i = 0; i < 4; ++i) r->s[i] = splitmix64(&x);
 }
+
+/* ---- the public mask stream (must stay identical to fheaes_mask_word in csrc/engine.hip) ---- */
+#define MASK_TAG_KSK 3
+#define MASK_TAG_BSK 4
+#define MASK_TAG_PFPKSK 5
+static inline uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static inline uint64_t mask_base(uint64_t mask_seed, uint64_t tag, uint64_t ct)
+{
+    return mix64(mask_seed ^ (tag * 0xD6E8FEB86659FD93ULL) ^ (ct * 0xA24BAED4963EE407ULL));
+}
+static inline uint64_t mask_word(uint64_t base, uint64_t j) { return mix64(base + (j + 1) * 0x9E3779B97F4A7C15ULL); }
+uint64_t fheaes_client_mask_word(uint64_t mask_seed, uint64_t tag, uint64_t ct, uint64_t j) { return mask_word(mask_base(mask_seed, tag, ct), j); }
 
 static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
 
@@ -103,11 +126,11 @@ static int build_positions(const uint8_t *bits, int *pos)
     return c;
 }
 
-/* fresh GLWE_S(0): mask uniform, body = sum A_m S_m + e */
-static void glwe_encrypt_zero(rng_t *r, int k, const int *pos, const int *npos, double sigma, uint64_t *ct)
+/* fresh GLWE_S(0): mask = public stream `mbase`, body = sum A_m S_m + e (noise from the secret stream r) */
+static void glwe_encrypt_zero(rng_t *r, uint64_t mbase, int k, const int *pos, const int *npos, double sigma, uint64_t *ct)
 {
     uint64_t *body = ct + (size_t)k * NPOLY;
-    for (int m = 0; m < k; ++m) for (int j = 0; j < NPOLY; ++j) ct[(size_t)m * NPOLY + j] = rng_next(r);
+    for (int j = 0; j < k * NPOLY; ++j) ct[j] = mask_word(mbase, (uint64_t)j);
     for (int j = 0; j < NPOLY; ++j) body[j] = noise_word(r, sigma);
     for (int m = 0; m < k; ++m) nega_mac_binary(ct + (size_t)m * NPOLY, pos + (size_t)m * NPOLY, npos[m], body);
 }
@@ -122,7 +145,7 @@ void fheaes_client_gen_secret_keys(const fheaes_params *p, uint64_t seed, uint8_
     for (uint32_t i = 0; i < p->glwe_dimension * NPOLY; ++i) glwe_sk[i] = (uint8_t)(rng_next(&r) >> 63);
 }
 
-void fheaes_client_gen_ksk(const fheaes_params *p, uint64_t seed, const uint8_t *lwe_sk, const uint8_t *glwe_sk,
+void fheaes_client_gen_ksk(const fheaes_params *p, uint64_t seed, uint64_t mask_seed, const uint8_t *lwe_sk, const uint8_t *glwe_sk,
                            double sigma_lwe, uint64_t *ksk)
 {
     int n = (int)p->lwe_dimension, big = (int)(p->glwe_dimension * NPOLY), L = (int)p->ks_level, b = (int)p->ks_base_log;
@@ -132,15 +155,16 @@ void fheaes_client_gen_ksk(const fheaes_params *p, uint64_t seed, const uint8_t 
         rng_seed(&r, seed, 3, (uint64_t)i);
         for (int l = 0; l < L; ++l) {
             uint64_t *row = ksk + ((size_t)i * L + l) * (n + 1);
+            const uint64_t mb = mask_base(mask_seed, MASK_TAG_KSK, (uint64_t)i * L + l);
             uint64_t body = noise_word(&r, sigma_lwe);
-            for (int j = 0; j < n; ++j) { row[j] = rng_next(&r); if (lwe_sk[j]) body += row[j]; }
+            for (int j = 0; j < n; ++j) { row[j] = mask_word(mb, (uint64_t)j); if (lwe_sk[j]) body += row[j]; }
             if (glwe_sk[i]) body += 1ULL << (64 - b * (l + 1));
             row[n] = body;
         }
     }
 }
 
-void fheaes_client_gen_bsk(const fheaes_params *p, uint64_t seed, const uint8_t *lwe_sk, const uint8_t *glwe_sk,
+void fheaes_client_gen_bsk(const fheaes_params *p, uint64_t seed, uint64_t mask_seed, const uint8_t *lwe_sk, const uint8_t *glwe_sk,
                            double sigma_glwe, uint64_t *bsk)
 {
     int n = (int)p->lwe_dimension, k = (int)p->glwe_dimension, k1 = k + 1, L = (int)p->pbs_level, b = (int)p->pbs_base_log;
@@ -153,15 +177,23 @@ void fheaes_client_gen_bsk(const fheaes_params *p, uint64_t seed, const uint8_t 
         rng_t r;
         rng_seed(&r, seed, 4, (uint64_t)i);
         for (int l = 0; l < L; ++l) for (int rr = 0; rr < k1; ++rr) {
-            uint64_t *ct = bsk + (((size_t)i * L + l) * k1 + rr) * gsz;
-            glwe_encrypt_zero(&r, k, pos, npos, sigma_glwe, ct);
-            if (lwe_sk[i]) ct[(size_t)rr * NPOLY] += 1ULL << (64 - b * (l + 1));
+            const size_t q = ((size_t)i * L + l) * k1 + rr;
+            uint64_t *ct = bsk + q * gsz;
+            glwe_encrypt_zero(&r, mask_base(mask_seed, MASK_TAG_BSK, (uint64_t)q), k, pos, npos, sigma_glwe, ct);
+            if (!lwe_sk[i]) continue;
+            /* row (l, r) carries s_i * g_l on component r.  The message goes into the BODY (row r < k: -g_l * S_r(X),
+             * row k: +g_l), never into a mask polynomial: same phase as adding g_l to mask coefficient 0 of polynomial r,
+             * and every mask word stays the public stream (seeded upload regenerates it). */
+            const uint64_t g = 1ULL << (64 - b * (l + 1));
+            uint64_t *body = ct + (size_t)k * NPOLY;
+            if (rr == k) body[0] += g;
+            else for (int j = 0; j < NPOLY; ++j) if (glwe_sk[(size_t)rr * NPOLY + j]) body[j] -= g;
         }
     }
     free(pos);
 }
 
-void fheaes_client_gen_pfpksk(const fheaes_params *p, uint64_t seed, const uint8_t *glwe_sk, double sigma_pfks, uint64_t *pfpksk)
+void fheaes_client_gen_pfpksk(const fheaes_params *p, uint64_t seed, uint64_t mask_seed, const uint8_t *glwe_sk, double sigma_pfks, uint64_t *pfpksk)
 {
     int k = (int)p->glwe_dimension, k1 = k + 1, L = (int)p->pfks_level, b = (int)p->pfks_base_log;
     int big = k * NPOLY, big1 = big + 1;
@@ -176,9 +208,10 @@ void fheaes_client_gen_pfpksk(const fheaes_params *p, uint64_t seed, const uint8
         /* sigma_i in {0, 1, -1} */
         int sig = (i < big) ? (int)glwe_sk[i] : -1;
         for (int l = 0; l < L; ++l) {
-            uint64_t *ct = pfpksk + (((size_t)rr * big1 + i) * L + l) * gsz;
+            const size_t q = ((size_t)rr * big1 + i) * L + l;
+            uint64_t *ct = pfpksk + q * gsz;
             uint64_t *body = ct + (size_t)k * NPOLY;
-            glwe_encrypt_zero(&r, k, pos, npos, sigma_pfks, ct);
+            glwe_encrypt_zero(&r, mask_base(mask_seed, MASK_TAG_PFPKSK, (uint64_t)q), k, pos, npos, sigma_pfks, ct);
             if (sig == 0) continue;
             uint64_t g = 1ULL << (64 - b * (l + 1));
             uint64_t x = (sig > 0) ? g : (uint64_t)0 - g;            /* sigma_i * g_l */

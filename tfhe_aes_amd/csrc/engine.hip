@@ -730,7 +730,10 @@ int fheaes_reserve(fheaes_ctx *c, uint64_t max_bits)
     return FHEAES_OK;
 }
 
-int fheaes_upload_keys(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, const uint64_t *pfpksk, int memspace)
+// Both uploads end in the same three conversions of the standard-domain words staged in HBM: KSK / PFPKSK -> balanced int8
+// byte planes in MFMA fragment order, BSK -> Fourier.  `seeded`: the caller passed bodies only and the masks are
+// regenerated on the GPU from the public mask seed (csrc/client.c) -- 0.19 GB over PCIe / xGMI instead of 1.04 GB.
+static int upload_keys_impl(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, const uint64_t *pfpksk, int memspace, bool seeded, uint64_t mask_seed)
 {
     if (!c || !ksk || !bsk || !pfpksk) return c ? c->fail(FHEAES_ERR_INVALID, "null key pointer") : FHEAES_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -747,39 +750,62 @@ int fheaes_upload_keys(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, 
     if (!c->pfpksk_frag) HIP_TRY(c, hipMalloc((void **)&c->pfpksk_frag, frag3));
     if (!c->bskf) HIP_TRY(c, hipMalloc((void **)&c->bskf, bw * 8));
     // stage the standard-domain words in HBM (largest key first), transform, free
-    void *tmp = nullptr;
+    void *tmp = nullptr, *tmp_body = nullptr;
     const size_t tmp_words = std::max(std::max(kw, bw), pw);
-    if (memspace != FHEAES_DEVICE) HIP_TRY(c, hipMalloc(&tmp, tmp_words * 8));
+    // seeded: key ciphertext counts and body sizes
+    const uint64_t cts[3] = {(uint64_t)rows1, (uint64_t)c->n * c->p.pbs_level * c->k1, (uint64_t)c->k1 * rows3};
+    const uint32_t mask_w[3] = {c->n, c->big, c->big}, body_w[3] = {1, FHE_N, FHE_N};
+    const uint64_t tags[3] = {3, 4, 5};                                  // MASK_TAG_* of csrc/client.c
+    size_t body_max = 0;
+    for (int i = 0; i < 3; ++i) body_max = std::max(body_max, (size_t)cts[i] * body_w[i]);
+    if (memspace != FHEAES_DEVICE || seeded) HIP_TRY(c, hipMalloc(&tmp, tmp_words * 8));
+    if (seeded && memspace != FHEAES_DEVICE) {
+        hipError_t me = hipMalloc(&tmp_body, body_max * 8);
+        if (me != hipSuccess) { (void)hipFree(tmp); return c->fail(FHEAES_ERR_NOMEM, "hipMalloc(%zu): %s", body_max * 8, hipGetErrorString(me)); }
+    }
     hipError_t copy_err = hipSuccess;
-    auto staged = [&](const uint64_t *src, size_t words) -> const uint64_t * {
-        if (memspace == FHEAES_DEVICE) return src;
-        hipError_t ce = hipMemcpyAsync(tmp, src, words * 8, hipMemcpyHostToDevice, c->stream);
-        if (ce != hipSuccess && copy_err == hipSuccess) copy_err = ce;
+    // which: 0 KSK, 1 BSK, 2 PFPKSK; returns the device pointer of the full standard-domain key
+    auto staged = [&](int which, const uint64_t *src, size_t words) -> const uint64_t * {
+        if (!seeded) {
+            if (memspace == FHEAES_DEVICE) return src;
+            hipError_t ce = hipMemcpyAsync(tmp, src, words * 8, hipMemcpyHostToDevice, c->stream);
+            if (ce != hipSuccess && copy_err == hipSuccess) copy_err = ce;
+            return (const uint64_t *)tmp;
+        }
+        const uint64_t *bodies = src;
+        if (memspace != FHEAES_DEVICE) {
+            hipError_t ce = hipMemcpyAsync(tmp_body, src, (size_t)cts[which] * body_w[which] * 8, hipMemcpyHostToDevice, c->stream);
+            if (ce != hipSuccess && copy_err == hipSuccess) copy_err = ce;
+            bodies = (const uint64_t *)tmp_body;
+        }
+        hipLaunchKernelGGL(expand_masks_kernel, dim3(8192), dim3(256), 0, c->stream, (uint64_t *)tmp, bodies, cts[which], mask_w[which], body_w[which],
+                           mask_seed, tags[which]);
         return (const uint64_t *)tmp;
     };
     int rc = FHEAES_OK;
     {
-        const uint64_t *d = staged(ksk, kw);
+        const uint64_t *d = staged(0, ksk, kw);
         const uint64_t threads = (uint64_t)c->ks_ksteps * c->ks_coltiles * 64;
         hipLaunchKernelGGL(keybytes_kernel, dim3((unsigned)((threads + 255) / 256), 1), dim3(256), 0, c->stream, d, (uint64_t)0, rows1, ncol1,
                            c->ks_ksteps, c->ks_coltiles, c->ksk_frag);
-        if (memspace != FHEAES_DEVICE) (void)hipStreamSynchronize(c->stream);
+        if (tmp) (void)hipStreamSynchronize(c->stream);
     }
     {
-        const uint64_t *d = staged(pfpksk, pw);
+        const uint64_t *d = staged(2, pfpksk, pw);
         const uint64_t threads = (uint64_t)c->pf_ksteps * c->pf_coltiles * 64;
         hipLaunchKernelGGL(keybytes_kernel, dim3((unsigned)((threads + 255) / 256), c->k1), dim3(256), 0, c->stream, d, (uint64_t)rows3 * ncol3, rows3, ncol3,
                            c->pf_ksteps, c->pf_coltiles, c->pfpksk_frag);
-        if (memspace != FHEAES_DEVICE) (void)hipStreamSynchronize(c->stream);
+        if (tmp) (void)hipStreamSynchronize(c->stream);
     }
     {
         // BSK: standard domain -> Fourier (the reference holds it in Fourier form already, many_wopbs.rs:34-35)
-        const uint64_t *d = staged(bsk, bw);
+        const uint64_t *d = staged(1, bsk, bw);
         rc = launch_forward_fourier(c, d, bw / FHE_N, c->bskf, FHEAES_STAGE_GGSW_FFT);
         c->stage_launches[FHEAES_STAGE_GGSW_FFT] = 0; c->stage_units[FHEAES_STAGE_GGSW_FFT] = 0;
     }
     hipError_t e = hipStreamSynchronize(c->stream);
     if (tmp) (void)hipFree(tmp);
+    if (tmp_body) (void)hipFree(tmp_body);
     if (rc != FHEAES_OK) return rc;
     if (copy_err != hipSuccess) return c->fail(FHEAES_ERR_DEVICE, "key upload (host -> device copy): %s", hipGetErrorString(copy_err));
     if (e != hipSuccess) return c->fail(FHEAES_ERR_DEVICE, "key upload: %s", hipGetErrorString(e));
@@ -788,6 +814,27 @@ int fheaes_upload_keys(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, 
     c->stage_ms[FHEAES_STAGE_GGSW_FFT] = 0;
     c->have_keys = true;
     return FHEAES_OK;
+}
+
+int fheaes_upload_keys(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, const uint64_t *pfpksk, int memspace)
+{
+    return upload_keys_impl(c, ksk, bsk, pfpksk, memspace, false, 0);
+}
+
+int fheaes_upload_keys_seeded(fheaes_ctx *c, uint64_t mask_seed, const uint64_t *ksk_body, const uint64_t *bsk_body, const uint64_t *pfpksk_body, int memspace)
+{
+    return upload_keys_impl(c, ksk_body, bsk_body, pfpksk_body, memspace, true, mask_seed);
+}
+
+size_t fheaes_key_body_words(const fheaes_ctx *c, int which)
+{
+    if (!c) return 0;
+    switch (which) {
+    case FHEAES_KEY_KSK: return (size_t)c->big * c->p.ks_level;
+    case FHEAES_KEY_BSK: return (size_t)c->n * c->p.pbs_level * c->k1 * FHE_N;
+    case FHEAES_KEY_PFPKSK: return (size_t)c->k1 * c->big1 * c->p.pfks_level * FHE_N;
+    default: return 0;
+    }
 }
 
 int fheaes_read_bsk_fourier(fheaes_ctx *c, uint32_t i, double *out)

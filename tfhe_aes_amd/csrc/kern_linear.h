@@ -99,3 +99,31 @@ __global__ __launch_bounds__(256) void counter_lut_kernel(uint64_t *luts, const 
         L[e] = (uint64_t)((val >> bit) & 1u) << 63;
     }
 }
+
+// ---- seeded evaluation keys (fheaes_upload_keys_seeded) -------------------------------------------------------------
+// Mask word j of key ciphertext q of key `tag` = the j-th output of the splitmix64 sequence started at
+// mix(mask_seed, tag, q): the public, counter-based stream of csrc/client.c (kept identical here).
+__device__ __host__ __forceinline__ uint64_t fheaes_mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __host__ __forceinline__ uint64_t fheaes_mask_word(uint64_t mask_seed, uint64_t tag, uint64_t q, uint64_t j)
+{
+    const uint64_t base = fheaes_mix64(mask_seed ^ (tag * 0xD6E8FEB86659FD93ULL) ^ (q * 0xA24BAED4963EE407ULL));
+    return fheaes_mix64(base + (j + 1) * 0x9E3779B97F4A7C15ULL);
+}
+
+// out [n_cts][mask_words + body_words] <- regenerated masks | bodies [n_cts][body_words]   (HBM-bound: one 8-byte store per word)
+__global__ __launch_bounds__(256) void expand_masks_kernel(uint64_t *out, const uint64_t *bodies, uint64_t n_cts, uint32_t mask_words,
+                                                           uint32_t body_words, uint64_t mask_seed, uint64_t tag)
+{
+    const uint32_t ct_words = mask_words + body_words;
+    const uint64_t total = n_cts * ct_words;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t q = i / ct_words;
+        const uint32_t j = (uint32_t)(i - q * ct_words);
+        out[i] = j < mask_words ? fheaes_mask_word(mask_seed, tag, q, j) : bodies[q * body_words + (j - mask_words)];
+    }
+}

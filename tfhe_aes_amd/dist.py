@@ -44,6 +44,38 @@ def broadcast_keys(params, keys, device, src: int = 0):
     return tensors
 
 
+def broadcast_keys_seeded(params, seeded, device, src: int = 0):
+    """The same, for keys in their compressed form (client.SeededServerKeys on rank `src`, None elsewhere): the public mask
+    seed and the three body arrays travel (0.19 GB instead of 1.04 GB at PARAM_OPT: one 8-byte and three tensor
+    broadcasts); every rank regenerates the masks on its own GPU (Engine.upload_keys_seeded).
+    Returns (mask_seed, [ksk_body, bsk_body, pfpksk_body]) with the bodies as int64 tensors on `device`."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    k, N = params.k, params.N
+    words = (params.big * params.ks_level, params.n * params.pbs_level * (k + 1) * N, (k + 1) * params.big1 * params.pfks_level * N)
+    seed_t = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == src:
+        if seeded is None:
+            raise ValueError("the source rank must hold the keys")
+        seed_t[0] = int(np.array([seeded.mask_seed], dtype=np.uint64).view(np.int64)[0])
+        tensors = [torch.from_numpy(np.ascontiguousarray(h).reshape(-1).view(np.int64)).to(device)
+                   for h in (seeded.ksk_body, seeded.bsk_body, seeded.pfpksk_body)]
+        for t, w in zip(tensors, words):
+            if t.numel() != w:
+                raise ValueError("key body size does not match the parameter set")
+    else:
+        tensors = [torch.empty(w, dtype=torch.int64, device=device) for w in words]
+    if world > 1:
+        dist.broadcast(seed_t, src=src)
+        for t in tensors:
+            dist.broadcast(t, src=src)
+    mask_seed = int(np.array([int(seed_t.item())], dtype=np.int64).view(np.uint64)[0])
+    return mask_seed, tensors
+
+
 def broadcast_tensor(t, src: int = 0):
     import torch.distributed as dist
 
