@@ -1,12 +1,27 @@
 //! Rust binding of include/fheaes.h and a `GpuServer` with the reference's method names
 //! (src/server/server.rs:32-274 of rostin79s/TFHE-AES).  UNCOMPILED sources (no Rust toolchain in the build
-//! image); the tfhe-rs accessor names follow tfhe 0.11.2 as used by the reference
-//! (many_wopbs.rs:34-35, :41, :76, :99-111, :168).
+//! image: never built, never run); the tfhe-rs accessor names follow tfhe 0.11.2 as used by the reference
+//! (many_wopbs.rs:34-35, :41, :76, :99-111, :168) and, where the reference does not show them, recall of the
+//! crate (marked UPSTREAM-RECALL).
+//!
+//! Which reference function each method replaces:
+//!   GpuServer::new                         Server::new                     src/server/server.rs:32
+//!   GpuServer::sbox                        sbox                            src/server/sbox/sbox.rs:46   (callers server.rs:60,77,101)
+//!   GpuServer::many_sbox                   many_sbox                       src/server/sbox/sbox.rs:68   (callers server.rs:48,89)
+//!   GpuServer::many_wopbs_without_padding  many_wopbs_without_padding      src/server/sbox/many_wopbs.rs:31
+//!   GpuServer::fhe_sub_word                fhe_sub_word                    src/server/key_expansion/key_expansion_utils.rs:24-28
+//!   GpuServer::aes_key_expansion           Server::aes_key_expansion       src/server/server.rs:107
+//!   GpuServer::aes_encrypt                 Server::aes_encrypt             src/server/server.rs:39   (batched over CTR blocks)
+//!   GpuServer::aes_decrypt                 Server::aes_decrypt             src/server/server.rs:67   (batched)
+//!   GpuServer::add_scalar                  Server::add_scalar              src/server/server.rs:172  (batched; carry defect of :182 fixed)
+//!   fourier_bsk_to_standard                (no counterpart: the reference only holds the Fourier BSK, many_wopbs.rs:34-35)
 #![allow(non_camel_case_types)]
 
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int};
 
+use tfhe::core_crypto::fft_impl::fft64::crypto::bootstrap::FourierLweBootstrapKeyOwned; // the type behind many_wopbs.rs:34-35
+use tfhe::core_crypto::fft_impl::fft64::math::fft::Fft;                                   // many_wopbs.rs:64
 use tfhe::core_crypto::prelude::*;
 use tfhe::integer::ciphertext::BaseRadixCiphertext;
 use tfhe::integer::IntegerCiphertext;
@@ -93,6 +108,64 @@ fn rewrap(words: &[u64], like: &Radix) -> Radix {
     Radix::from_blocks(blocks)
 }
 
+/// A whole AES state / key (16 bytes, index = 4*col + row, client.rs:126-129) -> 16 * 8 * lwe_size words
+fn flatten_state(state: &[Radix], out: &mut Vec<u64>) {
+    for b in state {
+        flatten_radix(b, out);
+    }
+}
+
+/// write `words` ([16][8][lwe_size]) back into the 16 radix bytes of `state` (metadata as many_wopbs.rs:87-115)
+fn rewrap_state(words: &[u64], state: &mut [Radix]) {
+    let byte_words = words.len() / state.len();
+    for (b, w) in state.iter_mut().zip(words.chunks_exact(byte_words)) {
+        *b = rewrap(w, b);
+    }
+}
+
+/// The engine wants the bootstrapping key in the STANDARD domain ([n][level][k+1][k+1][N] torus words, level 0 = most
+/// significant) and re-transforms it with its own FFT; the reference only holds tfhe-fft's Fourier image
+/// (`wopbs_key.wopbs_server_key.bootstrapping_key`, many_wopbs.rs:34-35).  Two ways to get the standard words:
+///   (a) preferred: keep the `LweBootstrapKeyOwned<u64>` that key generation produces before converting it -- a small change
+///       to `Client::new` (client.rs:106-107: build the ServerKey / WopbsKey from core_crypto pieces instead of
+///       `gen_keys_radix` + `WopbsKey::new_wopbs_key_only_for_wopbs`, which drop it);
+///   (b) this function: run tfhe-fft backwards over every polynomial of the Fourier key.  The round trip costs at most the
+///       f64 rounding of one forward + one backward transform per coefficient (~2^-50 relative, far below the key's
+///       noise of 2^-52 * 2^64 * sigma_glwe).
+/// UPSTREAM-RECALL: `FourierLweBootstrapKey::as_view().data()` is `[c64]` with the polynomials of every GGSW laid out
+/// [input bit][level][row][column][N/2]; `FftView::backward_as_torus` adds nothing and writes the rounded torus values.
+/// Both the level order inside a GGSW and the bit-reversed point order of tfhe-fft are internal to tfhe-rs, which is
+/// exactly why the inverse is done with tfhe-rs' own Fft here and not re-implemented.
+pub fn fourier_bsk_to_standard(fbsk: &FourierLweBootstrapKeyOwned, level_most_significant_first: bool) -> Vec<u64> {
+    let n = fbsk.input_lwe_dimension().0;
+    let glwe_size = fbsk.glwe_size().0;
+    let poly = fbsk.polynomial_size();
+    let levels = fbsk.decomposition_level_count().0;
+    let fft = Fft::new(poly);
+    let fft = fft.as_view();
+    let mut mem = dyn_stack::GlobalPodBuffer::new(fft.backward_scratch().unwrap());
+    let mut stack = dyn_stack::PodStack::new(&mut mem);
+    let half = poly.0 / 2;
+    let polys_per_ggsw = levels * glwe_size * glwe_size;
+    let mut out = vec![0u64; n * polys_per_ggsw * poly.0];
+    let view = fbsk.as_view();
+    let data = view.data();                                               // &[c64]
+    for i in 0..n {
+        for l in 0..levels {
+            // the engine's level index 0 is the most significant level; flip if tfhe-rs stores the least significant first
+            let l_src = if level_most_significant_first { l } else { levels - 1 - l };
+            for rc in 0..glwe_size * glwe_size {
+                let src = ((i * levels + l_src) * glwe_size * glwe_size + rc) * half;
+                let dst = ((i * levels + l) * glwe_size * glwe_size + rc) * poly.0;
+                let fourier = FourierPolynomial { data: &data[src..src + half] };
+                let mut torus = Polynomial::from_container(&mut out[dst..dst + poly.0]);
+                fft.backward_as_torus(torus.as_mut_view(), fourier, stack.rb_mut());
+            }
+        }
+    }
+    out
+}
+
 // ------------------------------------------------------------------------------------------------ GpuServer
 pub struct GpuServer {
     ctx: *mut fheaes_ctx,
@@ -100,8 +173,23 @@ pub struct GpuServer {
 unsafe impl Send for GpuServer {}
 
 impl GpuServer {
-    /// Server::new (server.rs:32).  `std_bsk` is the standard-domain bootstrapping key of the ServerKey
-    /// (keep it from key generation, or convert the Fourier key back with tfhe-rs); the engine re-transforms it.
+    /// Server::new (server.rs:32) from the reference's own key object alone: the Fourier BSK is taken back to the standard
+    /// domain with tfhe-rs' Fft (fourier_bsk_to_standard, route (b)).  UPSTREAM-RECALL: the Classic arm of
+    /// ShortintBootstrappingKey holds `bsk: FourierLweBootstrapKeyOwned` (the match of many_wopbs.rs:69-82).
+    pub fn from_wopbs_key(wopbs_key_short: &tfhe::shortint::wopbs::WopbsKey, device: i32) -> Self {
+        use tfhe::shortint::server_key::ShortintBootstrappingKey;
+        let std_words = match &wopbs_key_short.wopbs_server_key.bootstrapping_key {
+            ShortintBootstrappingKey::Classic(fbsk) => fourier_bsk_to_standard(fbsk, true),
+            ShortintBootstrappingKey::MultiBit { .. } => panic!("multi-bit bootstrapping keys are not on this path (many_wopbs.rs:83-84 is a no-op)"),
+        };
+        let p = wopbs_key_short.param;
+        let std_bsk = LweBootstrapKeyOwned::from_container(std_words, p.glwe_dimension.to_glwe_size(), p.polynomial_size, p.pbs_base_log,
+                                                           p.pbs_level, wopbs_key_short.wopbs_server_key.ciphertext_modulus);
+        Self::new(wopbs_key_short, &std_bsk, device)
+    }
+
+    /// Server::new (server.rs:32).  `std_bsk` is the standard-domain bootstrapping key (route (a) of
+    /// fourier_bsk_to_standard: kept from key generation); the engine re-transforms it on upload.
     pub fn new(wopbs_key_short: &tfhe::shortint::wopbs::WopbsKey, std_bsk: &LweBootstrapKeyOwned<u64>, device: i32) -> Self {
         let p: WopbsParameters = wopbs_key_short.param;
         let params = fheaes_params {
@@ -175,8 +263,93 @@ impl GpuServer {
             }
         }
     }
-    // aes_decrypt, aes_key_expansion and add_scalar follow the same flatten -> call -> rewrap pattern
-    // (fheaes_aes_decrypt, fheaes_aes_key_expansion, fheaes_add_scalar).
+
+    /// sbox (sbox.rs:46), in place on one byte: the engine holds the {SBOX} / {INV_SBOX} LUT sets, so neither `gen_lut`
+    /// (sbox.rs:54-60) nor the integer WopbsKey argument is needed.  Callers: server.rs:60, :77, :101.
+    pub fn sbox(&self, ct_in: &mut Radix, inv: bool) {
+        let mut flat = Vec::new();
+        flatten_radix(ct_in, &mut flat);
+        let rc = unsafe { fheaes_sbox(self.ctx, flat.as_mut_ptr(), 1, inv as c_int, FHEAES_HOST) };
+        assert!(rc == 0, "{}", self.last_error());
+        *ct_in = rewrap(&flat, ct_in);
+    }
+
+    /// The same over a whole vector of bytes in ONE launch sequence (16 * n_blocks bytes of an AES round): what the
+    /// loops of server.rs:59-61 / :76-78 / :100-102 should call instead of 16 separate `sbox`.
+    pub fn sbox_many_bytes(&self, bytes: &mut [Radix], inv: bool) {
+        let mut flat = Vec::new();
+        flatten_state(bytes, &mut flat);
+        let rc = unsafe { fheaes_sbox(self.ctx, flat.as_mut_ptr(), bytes.len() as u64, inv as c_int, FHEAES_HOST) };
+        assert!(rc == 0, "{}", self.last_error());
+        rewrap_state(&flat, bytes);
+    }
+
+    /// many_sbox (sbox.rs:68): one set of 8 circuit bootstraps, 3 LUTs {S, 2S, 3S} (inv = false, consumed positionally by
+    /// mix_columns.rs:36-75) or 4 LUTs {9x, 11x, 13x, 14x} (inv = true, inv_mix_columns.rs:17-55).  Callers: server.rs:48, :89.
+    pub fn many_sbox(&self, ct_in: &Radix, inv: bool) -> Vec<Radix> {
+        let n_luts = if inv { 4 } else { 3 };
+        let mut flat = Vec::new();
+        flatten_radix(ct_in, &mut flat);
+        let mut out = vec![0u64; n_luts * flat.len()];
+        let rc = unsafe { fheaes_many_sbox(self.ctx, flat.as_ptr(), 1, inv as c_int, out.as_mut_ptr(), FHEAES_HOST) };
+        assert!(rc == 0, "{}", self.last_error());
+        out.chunks_exact(flat.len()).map(|w| rewrap(w, ct_in)).collect()
+    }
+
+    /// fhe_sub_word (key_expansion_utils.rs:24-28): SBOX on the 4 bytes of a key-schedule word, one call
+    pub fn fhe_sub_word(&self, word: &mut [Radix]) {
+        self.sbox_many_bytes(word, false);
+    }
+
+    /// Server::aes_key_expansion (server.rs:107): encrypted key [16 bytes] -> 11 round keys.  RCON enters as a trivial
+    /// encoding inside the engine (the reference encrypts it with the public key, server.rs:138-143: same plaintext effect).
+    pub fn aes_key_expansion(&self, key: &[Radix]) -> Vec<Vec<Radix>> {
+        let mut flat = Vec::new();
+        flatten_state(key, &mut flat);
+        let mut rk = vec![0u64; 11 * flat.len()];
+        let rc = unsafe { fheaes_aes_key_expansion(self.ctx, flat.as_ptr(), rk.as_mut_ptr(), FHEAES_HOST) };
+        assert!(rc == 0, "{}", self.last_error());
+        let byte_words = flat.len() / key.len();
+        rk.chunks_exact(flat.len())
+            .map(|round| round.chunks_exact(byte_words).zip(key.iter()).map(|(w, like)| rewrap(w, like)).collect())
+            .collect()
+    }
+
+    /// Server::aes_decrypt (server.rs:67) over a whole vector of blocks in one call
+    pub fn aes_decrypt(&self, round_keys: &[Vec<Radix>], states: &mut [Vec<Radix>]) {
+        let mut rk = Vec::new();
+        for r in round_keys {
+            flatten_state(r, &mut rk);
+        }
+        let mut st = Vec::new();
+        for s in states.iter() {
+            flatten_state(s, &mut st);
+        }
+        let rc = unsafe { fheaes_aes_decrypt(self.ctx, rk.as_ptr(), st.as_mut_ptr(), states.len() as u64, FHEAES_HOST) };
+        assert!(rc == 0, "{}", self.last_error());
+        let state_words = st.len() / states.len();
+        for (s, words) in states.iter_mut().zip(st.chunks_exact(state_words)) {
+            rewrap_state(words, s);
+        }
+    }
+
+    /// Server::add_scalar (server.rs:172) for a vector of blocks: states[b] += counters[b] (the CTR loop of main.rs:59-61
+    /// calls it with the block index).  The engine derives the first-byte carry from `counter & 0xFF`; server.rs:182 uses
+    /// the whole counter and is wrong for counters >= 256.
+    pub fn add_scalar(&self, states: &mut [Vec<Radix>], counters: &[u128]) {
+        assert_eq!(states.len(), counters.len());
+        let mut st = Vec::new();
+        for s in states.iter() {
+            flatten_state(s, &mut st);
+        }
+        let hi_lo: Vec<u64> = counters.iter().flat_map(|c| [(c >> 64) as u64, *c as u64]).collect();
+        let rc = unsafe { fheaes_add_scalar(self.ctx, st.as_mut_ptr(), states.len() as u64, hi_lo.as_ptr(), FHEAES_HOST) };
+        assert!(rc == 0, "{}", self.last_error());
+        let state_words = st.len() / states.len();
+        for (s, words) in states.iter_mut().zip(st.chunks_exact(state_words)) {
+            rewrap_state(words, s);
+        }
+    }
 }
 
 impl Drop for GpuServer {
