@@ -28,6 +28,10 @@ VARIANTS = {
     "b16_noxpose": ["-DBR16_ABL_NOXPOSE"],
     "b16_nofft_nomac_noload": ["-DBR16_ABL_NOFFT", "-DBR16_ABL_NOMAC", "-DBR16_ABL_NOLOAD"],
     "b16_xprio0": ["-DFFT_XPOSE_PRIO=0"],
+    "b16_prio1": ["-DBR16_MAC_PRIO=1"],
+    "rot2": ["-DEP_ROT_CHUNK=2"],
+    "rot8": ["-DEP_ROT_CHUNK=8"],
+    "rot16": ["-DEP_ROT_CHUNK=16"],
     "one_wg": ["-DBR32_PAD_CPLX=2048"],
     "one_wg_stamps": ["-DBR32_PAD_CPLX=2048", "-DEP_STAMPS"],
     "b32_prio0": ["-DBR32_MAC_PRIO=0"],
