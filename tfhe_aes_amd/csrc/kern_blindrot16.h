@@ -67,7 +67,10 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
 {
     static_assert(R * K1 <= EP_GROUPS, "too many polynomials for 16 lane groups");
     // twiddle tables first: their addresses then fit the 16-bit offset field of the LDS instructions
-    __shared__ __attribute__((aligned(16))) double lds_all[EP_LDS_DOUBLES];
+#ifndef BR16_PAD_DOUBLES
+#define BR16_PAD_DOUBLES 0     /* developer ablation: extra LDS so that only one workgroup fits a CU */
+#endif
+    __shared__ __attribute__((aligned(16))) double lds_all[EP_LDS_DOUBLES + BR16_PAD_DOUBLES];
     double2 *psi = reinterpret_cast<double2 *>(lds_all);
     double2 *tw = psi + FHE_H;
     double *lds = lds_all + 2 * 2 * FHE_H;                        // the 16 group tiles

@@ -21,6 +21,8 @@ VARIANTS = {
     "old16": ["-DPBS_FORM16=0"],
     "form32": ["-DPBS_FORM32=1"],
     "b16_prio0": ["-DBR16_MAC_PRIO=0"],
+    "b16_one_wg": ["-DBR16_PAD_DOUBLES=2048"],
+    "b16_one_wg_stamps": ["-DBR16_PAD_DOUBLES=2048", "-DEP_STAMPS"],
     "b16_noload": ["-DBR16_ABL_NOLOAD"],
     "b16_nomac": ["-DBR16_ABL_NOMAC"],
     "b16_nomac_noload": ["-DBR16_ABL_NOMAC", "-DBR16_ABL_NOLOAD"],
