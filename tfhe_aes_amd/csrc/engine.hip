@@ -382,6 +382,9 @@ int launch_forward_fourier(fheaes_ctx *c, const uint64_t *in, uint64_t polys, do
 int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_t level, uint64_t *out)
 {
     if (m == 0) return FHEAES_OK;
+    // the blind-rotation kernels address the Fourier BSK as ONE raw buffer with 32-bit byte offsets
+    if ((uint64_t)c->n * c->p.pbs_level * c->k1 * c->k1 * FHE_H * 16 > 0x7FFFFFFFull)
+        return c->fail(FHEAES_ERR_INVALID, "bootstrapping key larger than 2 GiB is not supported by the blind-rotation kernels");
     StageScope sc(c, FHEAES_STAGE_BLIND_ROTATE, m);
     ExtProdArgs a{};
     a.ggsw = c->bskf; a.psi = c->psi_d; a.tw = c->tw_d; a.fc = c->fc;
@@ -393,6 +396,12 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
 #endif
     if (m <= LATENCY_BATCH_BITS) {
         // latency regime: one ciphertext per 512-thread workgroup, all levels transformed at once (kern_blindrot_latency.h)
+#ifdef EP_STAMPS
+        static const char *namesL[EP_NPH] = {"top: key loads issued", "rotate+decompose", "forward fft", "digit stores", "barrier (digits)", "MAC", "barrier (MAC done)",
+                                             "products store", "barrier (products)", "inverse fft + accumulate", "barrier (acc)", "-"};
+        StampReport rep(c, (size_t)m * 8, namesL);
+        a.stamps = rep.d;
+#endif
         if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate_latency_kernel<5, 5, 8>), dim3((unsigned)m), dim3(BL_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((blind_rotate_latency_kernel<2, 5, 8>), dim3((unsigned)m), dim3(BL_THREADS), 0, c->stream, a);
     } else if (c->k1 == 5 && m <= SMALL_BATCH_BITS) {

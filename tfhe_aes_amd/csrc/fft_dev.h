@@ -178,6 +178,66 @@ __device__ __forceinline__ void nega_inv(double (&xr)[16], double (&xi)[16], con
     }
 }
 
+// ---- the same transforms with the table reads batched -----------------------------------------------------------------
+// With one or two waves per SIMD nothing hides an LDS round trip but the wave's own instruction stream, and the compiler
+// keeps a single table read in flight when registers are tight (each of the 31 reads of a transform then exposes ~100
+// cycles).  These forms read eight table entries at a time into a buffer, one step ahead of their use.  Identical arithmetic.
+__device__ __forceinline__ void fft_tw_load8(double2 (&w)[8], const double2 *tab, int base, int stride)
+{
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = tab[base + stride * k];
+}
+template <bool CONJ, int N>
+__device__ __forceinline__ void fft_tw_mul(double *xr, double *xi, const double2 (&w)[8], int first = 0)
+{
+#pragma unroll
+    for (int k = first; k < N; ++k) {
+        if (!CONJ) cmul(xr[k], xi[k], w[k].x, w[k].y); else cmulc(xr[k], xi[k], w[k].x, w[k].y);
+    }
+}
+
+// forward: w0 must already hold psi[16a + b], a = 0..7 (fft_tw_load8(w0, psi, b, 16), issued before the digits were made)
+__device__ __forceinline__ void nega_fwd_batched(double (&xr)[16], double (&xi)[16], double2 (&w0)[8], double2 (&w1)[8], const double2 *psi,
+                                                 const double2 *tw, double *tile, int b, const FftConsts fc)
+{
+    fft_tw_load8(w1, psi, 128 + b, 16);                 // a = 8..15
+    __builtin_amdgcn_sched_barrier(0);
+    fft_tw_mul<false, 8>(xr, xi, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    fft_tw_load8(w0, tw, 16 + b, 16);                   // w256^(k1 b), k1 = 1..8
+    __builtin_amdgcn_sched_barrier(0);
+    fft_tw_mul<false, 8>(xr + 8, xi + 8, w1);
+    __builtin_amdgcn_sched_barrier(0);
+    fft_tw_load8(w1, tw, 128 + b, 16);                  // k1 = 8..15 (entry 0 unused)
+    __builtin_amdgcn_sched_barrier(0);
+    dft16<false>(xr, xi, fc);
+    __builtin_amdgcn_sched_barrier(0);
+    fft_tw_mul<false, 8>(xr + 1, xi + 1, w0);
+    fft_tw_mul<false, 8>(xr + 8, xi + 8, w1, 1);
+    nega_fwd_tail(xr, xi, tile, b, fc);
+}
+
+__device__ __forceinline__ void nega_inv_batched(double (&xr)[16], double (&xi)[16], double2 (&w0)[8], double2 (&w1)[8], const double2 *psi,
+                                                 const double2 *tw, double *tile, int b, const FftConsts fc)
+{
+    fft_tw_load8(w0, tw, 16 + b, 16);                   // k1 = 1..8
+    fft_tw_load8(w1, tw, 128 + b, 16);                  // k1 = 8..15
+    __builtin_amdgcn_sched_barrier(0);
+    dft16<true>(xr, xi, fc);
+    __builtin_amdgcn_sched_barrier(0);
+    fft_tw_mul<true, 8>(xr + 1, xi + 1, w0);
+    fft_tw_mul<true, 8>(xr + 8, xi + 8, w1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fft_tw_load8(w0, psi, b, 16);
+    fft_tw_load8(w1, psi, 128 + b, 16);
+    __builtin_amdgcn_sched_barrier(0);
+    group_transpose(xr, xi, tile, b);
+    dft16<true>(xr, xi, fc);
+    __builtin_amdgcn_sched_barrier(0);
+    fft_tw_mul<true, 8>(xr, xi, w0);
+    fft_tw_mul<true, 8>(xr + 8, xi + 8, w1);
+}
+
 __device__ __forceinline__ uint64_t torus_from_double(double v)
 {
     double w = v * 0x1p-72;

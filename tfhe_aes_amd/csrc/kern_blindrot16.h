@@ -28,38 +28,11 @@
 #endif
 #define BR16_PARK_WORDS_PER_WG (16 * EP_THREADS * 2 * 2)   /* 16 chunks of 32 bytes per thread: lo[a], hi[a] pairs */
 
-// One 16-byte key element through a raw buffer load: the address is (buffer base, scalar) + (row offset, scalar) +
-// (16 * point, the only vector part), so a key fetch costs no vector address arithmetic at all.
-typedef unsigned br16_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ double2 br16_key_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_bytes, unsigned row_bytes)
-{
-    br16_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, row_bytes, 0);
-    double2 d;
-    d.x = __longlong_as_double((long long)(((unsigned long long)v[1] << 32) | v[0]));
-    d.y = __longlong_as_double((long long)(((unsigned long long)v[3] << 32) | v[2]));
-    return d;
-}
-
 __device__ __forceinline__ int br16_opaque_tid()
 {
     int t = threadIdx.x;
     asm volatile("" : "+v"(t));
     return t;
-}
-
-// eight table entries tab[base + stride * k], k = 0..7, requested together
-__device__ __forceinline__ void br16_tw_load(double2 (&w)[8], const double2 *tab, int base, int stride)
-{
-#pragma unroll
-    for (int k = 0; k < 8; ++k) w[k] = tab[base + stride * k];
-}
-template <bool CONJ, int N>
-__device__ __forceinline__ void br16_tw_mul(double *xr, double *xi, const double2 (&w)[8])
-{
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        if (!CONJ) cmul(xr[k], xi[k], w[k].x, w[k].y); else cmulc(xr[k], xi[k], w[k].x, w[k].y);
-    }
 }
 
 template <int K1, int LEVELS, int BASE_LOG, int R>
@@ -107,6 +80,13 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
     }
     ulonglong2 *park = reinterpret_cast<ulonglong2 *>(A.park) + (size_t)blockIdx.x * 16 * EP_THREADS;   // wave-uniform
     __syncthreads();   // tables visible
+#if defined(BR16_STAGGER_SLEEP) && BR16_STAGGER_SLEEP > 0
+    // developer experiment: start every second generation of workgroups a fraction of a level later, so that the two
+    // workgroups of a CU run their key-load phase and their transform phase against each other instead of in phase
+    if ((blockIdx.x >> BR16_STAGGER_SHIFT) & 1) {
+        for (int i = 0; i < BR16_STAGGER_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 
     constexpr unsigned GGSW_BYTES = LEVELS * K1 * K1 * FHE_H * 16;   // one GGSW of the Fourier BSK
     // the whole Fourier BSK as one raw buffer (< 2^31 bytes for every supported parameter set: checked by the launcher)
@@ -140,7 +120,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
 #pragma unroll
             for (int a = 0; a < 16; ++a) { ulonglong2 v; v.x = lo[a]; v.y = hi[a]; (park + a * EP_THREADS)[(unsigned)tq] = v; }
             wave_lds_sync();
-            br16_tw_load(w0, psi, bq_, 16);                       // psi^(16a+b), a = 0..7: lands during the rotation
+            fft_tw_load8(w0, psi, bq_, 16);                       // psi^(16a+b), a = 0..7: lands during the rotation
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
@@ -171,21 +151,21 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
             double *tile = lds + (tq >> 4) * GROUP_TILE_DOUBLES;
             // ---- forward transform: fold + twist, DFT16, twiddle, transpose, DFT16 (fft_dev.h's nega_fwd, with the
             //      table reads batched eight at a time and issued one step ahead) ------------------------------------
-            br16_tw_load(w1, psi, 128 + bq_, 16);                  // a = 8..15
+            fft_tw_load8(w1, psi, 128 + bq_, 16);                  // a = 8..15
             __builtin_amdgcn_sched_barrier(0);
-            br16_tw_mul<false, 8>(xr, xi, w0);
+            fft_tw_mul<false, 8>(xr, xi, w0);
             __builtin_amdgcn_sched_barrier(0);
-            br16_tw_load(w0, tw, 16 + bq_, 16);                    // w256^(k1 b), k1 = 1..8
+            fft_tw_load8(w0, tw, 16 + bq_, 16);                    // w256^(k1 b), k1 = 1..8
             __builtin_amdgcn_sched_barrier(0);
-            br16_tw_mul<false, 8>(xr + 8, xi + 8, w1);
+            fft_tw_mul<false, 8>(xr + 8, xi + 8, w1);
             __builtin_amdgcn_sched_barrier(0);
-            br16_tw_load(w1, tw, 128 + bq_, 16);                   // k1 = 8..15 (entry 0 unused)
+            fft_tw_load8(w1, tw, 128 + bq_, 16);                   // k1 = 8..15 (entry 0 unused)
             __builtin_amdgcn_sched_barrier(0);
 #ifndef BR16_ABL_NOFFT
             dft16<false>(xr, xi, fc);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            br16_tw_mul<false, 8>(xr + 1, xi + 1, w0);
+            fft_tw_mul<false, 8>(xr + 1, xi + 1, w0);
 #pragma unroll
             for (int k = 1; k < 8; ++k) cmul(xr[8 + k], xi[8 + k], w1[k].x, w1[k].y);
             EP_STAMP(2);
@@ -215,7 +195,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
 #ifdef BR16_ABL_NOLOAD
                 for (int c = 0; c < K1; ++c) bm[p][c] = make_double2((double)(tq + c + p), (double)(tq - c));
 #else
-                for (int c = 0; c < K1; ++c) bm[p][c] = br16_key_load(bsk_rsrc, (unsigned)tq * 16u, gl_bytes + (unsigned)(p * K1 + c) * (FHE_H * 16));
+                for (int c = 0; c < K1; ++c) bm[p][c] = ep_key_load(bsk_rsrc, (unsigned)tq * 16u, gl_bytes + (unsigned)(p * K1 + c) * (FHE_H * 16));
 #endif
             __builtin_amdgcn_sched_barrier(0);
             EP_STAMP(5);
@@ -264,7 +244,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
         for (int l = LEVELS - 2; l >= 0; --l) {
             {
                 const int tq = br16_opaque_tid();
-                br16_tw_load(w0, psi, tq & 15, 16);               // lands during the decomposition step
+                fft_tw_load8(w0, psi, tq & 15, 16);               // lands during the decomposition step
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -298,25 +278,25 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
             double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ + 16 * k2));
             xr[k2] = v.x; xi[k2] = v.y;
         }
-        br16_tw_load(w0, tw, 16 + bq_, 16);                       // k1 = 1..8
-        br16_tw_load(w1, tw, 128 + bq_, 16);                      // k1 = 8..15
+        fft_tw_load8(w0, tw, 16 + bq_, 16);                       // k1 = 1..8
+        fft_tw_load8(w1, tw, 128 + bq_, 16);                      // k1 = 8..15
         wave_lds_sync();
         EP_STAMP(8);
         // inverse transform (fft_dev.h's nega_inv, table reads batched and issued a step ahead)
         dft16<true>(xr, xi, fc);
         __builtin_amdgcn_sched_barrier(0);
-        br16_tw_mul<true, 8>(xr + 1, xi + 1, w0);
+        fft_tw_mul<true, 8>(xr + 1, xi + 1, w0);
 #pragma unroll
         for (int k = 1; k < 8; ++k) cmulc(xr[8 + k], xi[8 + k], w1[k].x, w1[k].y);
         __builtin_amdgcn_sched_barrier(0);
-        br16_tw_load(w0, psi, bq_, 16);
-        br16_tw_load(w1, psi, 128 + bq_, 16);
+        fft_tw_load8(w0, psi, bq_, 16);
+        fft_tw_load8(w1, psi, 128 + bq_, 16);
         __builtin_amdgcn_sched_barrier(0);
         group_transpose(xr, xi, tile, bq_);
         dft16<true>(xr, xi, fc);
         __builtin_amdgcn_sched_barrier(0);
-        br16_tw_mul<true, 8>(xr, xi, w0);
-        br16_tw_mul<true, 8>(xr + 8, xi + 8, w1);
+        fft_tw_mul<true, 8>(xr, xi, w0);
+        fft_tw_mul<true, 8>(xr + 8, xi + 8, w1);
         EP_STAMP(9);
 #pragma unroll
         for (int a = 0; a < 16; ++a) {

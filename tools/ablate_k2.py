@@ -21,6 +21,14 @@ VARIANTS = {
     "old16": ["-DPBS_FORM16=0"],
     "form32": ["-DPBS_FORM32=1"],
     "b16_prio0": ["-DBR16_MAC_PRIO=0"],
+    "stag8_1": ["-DBR16_STAGGER_SHIFT=8", "-DBR16_STAGGER_SLEEP=1"],
+    "stag8_2": ["-DBR16_STAGGER_SHIFT=8", "-DBR16_STAGGER_SLEEP=2"],
+    "stag8_4": ["-DBR16_STAGGER_SHIFT=8", "-DBR16_STAGGER_SLEEP=4"],
+    "stag0_1": ["-DBR16_STAGGER_SHIFT=0", "-DBR16_STAGGER_SLEEP=1"],
+    "stag3_1": ["-DBR16_STAGGER_SHIFT=3", "-DBR16_STAGGER_SLEEP=1"],
+    "stag5_1": ["-DBR16_STAGGER_SHIFT=5", "-DBR16_STAGGER_SLEEP=1"],
+    "stag7_1": ["-DBR16_STAGGER_SHIFT=7", "-DBR16_STAGGER_SLEEP=1"],
+    "stag9_1": ["-DBR16_STAGGER_SHIFT=9", "-DBR16_STAGGER_SLEEP=1"],
     "b16_one_wg": ["-DBR16_PAD_DOUBLES=2048"],
     "b16_one_wg_stamps": ["-DBR16_PAD_DOUBLES=2048", "-DEP_STAMPS"],
     "b16_noload": ["-DBR16_ABL_NOLOAD"],
