@@ -166,7 +166,7 @@ def main():
     mask_seed, dbodies = broadcast_keys_seeded(p, seeded, dev, src=0)
     torch.cuda.synchronize()
     bcast_s = time.time() - t0
-    key_bytes_moved = sum(int(t.numel()) * 8 for t in dbodies) + 8
+    key_bytes_moved = sum(int(t.numel()) * 8 for t in dbodies) + 32
     eng = _native.Engine(p, device=dev_index)
     t0 = time.time()
     eng.upload_keys_seeded(mask_seed, *dbodies)

@@ -76,14 +76,16 @@ size_t fheaes_key_words(const fheaes_ctx *ctx, int which);
  * Level index 0 is the most significant level (weight 2^(64-base_log)). */
 int fheaes_upload_keys(fheaes_ctx *ctx, const uint64_t *ksk, const uint64_t *bsk, const uint64_t *pfpksk, int memspace);
 
-/* The same keys as (public mask seed, bodies): every mask word of the three keys is the output of a counter-based public
- * stream (mask word j of key ciphertext q of key t = splitmix64 sequence started at mix(mask_seed, t, q): csrc/client.c),
- * so only the bodies travel -- KSK [kN][ks_level] words, BSK [n][pbs_level][k+1][N], PFPKSK [k+1][kN+1][pfks_level][N]:
- * 0.19 GB instead of 1.04 GB at PARAM_OPT -- and the masks are regenerated on the GPU.  The counterpart in the reference's
- * world are tfhe-rs' Seeded* key containers, which client.rs:106-107 does not use (it builds full keys in memory and hands
- * them over by value, server.rs:32); device keys are bit-identical to fheaes_upload_keys of the expanded keys. */
+/* The same keys as (public mask key, bodies): every mask word of the three keys is the output of a public, counter-based
+ * ChaCha20 stream -- mask word j of key ciphertext q of key t (t = 3 KSK, 4 BSK, 5 PFPKSK) is 64-bit word j % 8 of the
+ * RFC 8439 block j / 8 under (mask_key, nonce = (t, q)) (csrc/client.c) -- so only the bodies travel: KSK [kN][ks_level]
+ * words, BSK [n][pbs_level][k+1][N], PFPKSK [k+1][kN+1][pfks_level][N]: 0.19 GB instead of 1.04 GB at PARAM_OPT, and the masks
+ * are regenerated on the GPU.  `mask_key` is a HOST array of 8 uint32 (256 bits) whatever `memspace` says about the bodies.
+ * The counterpart in the reference's world are tfhe-rs' Seeded* key containers, which client.rs:106-107 does not use (it builds
+ * full keys in memory and hands them over by value, server.rs:32); device keys are bit-identical to fheaes_upload_keys of the
+ * expanded keys. */
 size_t fheaes_key_body_words(const fheaes_ctx *ctx, int which);
-int fheaes_upload_keys_seeded(fheaes_ctx *ctx, uint64_t mask_seed, const uint64_t *ksk_body, const uint64_t *bsk_body,
+int fheaes_upload_keys_seeded(fheaes_ctx *ctx, const uint32_t *mask_key, const uint64_t *ksk_body, const uint64_t *bsk_body,
                               const uint64_t *pfpksk_body, int memspace);
 
 /* ---- stream / sync / workspace ------------------------------------------------- */

@@ -1,5 +1,5 @@
-"""Seeded evaluation keys (first slice): keys travel as (public mask seed, bodies) and every mask word
-is regenerated -- on the host by SeededServerKeys.expand(), on the GPU by fheaes_upload_keys_seeded."""
+"""Seeded evaluation keys (first slice): keys travel as (public 256-bit mask key, bodies) and every mask word
+is regenerated from a ChaCha20 stream -- on the host by SeededServerKeys.expand(), on the GPU by fheaes_upload_keys_seeded."""
 import ctypes
 
 import numpy as np
@@ -9,11 +9,41 @@ from tfhe_aes_amd import client as cl
 from tfhe_aes_amd.client import SeededServerKeys, ServerKeys
 
 
+def test_chacha20_block_known_answer():
+    """RFC 8439 section 2.3.2: key 00..1f, counter 1, nonce 00:00:00:09:00:00:00:4a:00:00:00:00 -- the C generator
+    (csrc/client.c) and its numpy twin (client.chacha20_blocks) both give the published block"""
+    want = np.array([0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3, 0xc7f4d1c7, 0x0368c033, 0x9aaa2204, 0x4e6cd4c3,
+                     0x466482d2, 0x09aa9f07, 0x05d7c214, 0xa2028bd9, 0xd19c12b5, 0xb94e16de, 0xe883d0cb, 0x4e3c50a2], dtype=np.uint32)
+    key = np.frombuffer(bytes(range(32)), dtype=np.uint32).copy()
+    nonce = np.array([0x09000000, 0x4a000000, 0], dtype=np.uint32)
+    out = np.zeros(16, dtype=np.uint32)
+    cl._load().fheaes_client_chacha20_block(cl._u32(key), 1, cl._u32(nonce), cl._u32(out))
+    assert np.array_equal(out, want)
+    w = cl.chacha20_blocks(key, np.array([1], dtype=np.uint32), 0x09000000, np.array([0x4a000000], dtype=np.uint32), np.array([0], dtype=np.uint32))
+    assert np.array_equal(w[0], want)
+
+
 def test_mask_stream_numpy_matches_c():
     lib = cl._load()
-    w = cl.mask_words(0x1234567890ABCDEF, cl.MASK_TAG_BSK, 7, 40)
+    key = cl.test_key(0x1234567890ABCDEF, 2)
+    w = cl.mask_words(key, cl.MASK_TAG_BSK, 7, 40)
     for q, j in ((0, 0), (3, 17), (6, 39)):
-        assert int(w[q, j]) == lib.fheaes_client_mask_word(0x1234567890ABCDEF, cl.MASK_TAG_BSK, q, j)
+        assert int(w[q, j]) == lib.fheaes_client_mask_word(cl._u32(key), cl.MASK_TAG_BSK, q, j)
+
+
+def test_default_client_draws_fresh_keys():
+    """Client() without a seed: secret, mask and per-encryption keys come from os.urandom; an explicit seed is the
+    reproducible test mode"""
+    from tfhe_aes_amd import PARAM_TOY
+
+    a, b = cl.Client(params=PARAM_TOY), cl.Client(params=PARAM_TOY)
+    assert not a.deterministic and not np.array_equal(a.seed, b.seed) and not np.array_equal(a.mask_seed, b.mask_seed)
+    assert not np.array_equal(a.seed, a.mask_seed)
+    x1, x2 = a.encrypt_bits(np.array([1, 0], dtype=np.uint8)), a.encrypt_bits(np.array([1, 0], dtype=np.uint8))
+    assert not np.array_equal(x1, x2) and list(a.decrypt_bits(x1)) == [1, 0] and list(a.decrypt_bits(x2)) == [1, 0]
+    c, d = cl.Client(params=PARAM_TOY, seed=7), cl.Client(params=PARAM_TOY, seed=7)
+    assert c.deterministic and np.array_equal(c.glwe_sk, d.glwe_sk)
+    assert np.array_equal(c.encrypt_bits(np.array([1], dtype=np.uint8)), d.encrypt_bits(np.array([1], dtype=np.uint8)))
 
 
 def test_compress_expand_roundtrip_and_sizes(toy, tmp_path):
@@ -26,7 +56,7 @@ def test_compress_expand_roundtrip_and_sizes(toy, tmp_path):
     # file round trip (npz of uint64 arrays, no pickle)
     sk.save(tmp_path / "k.npz")
     back = SeededServerKeys.load(tmp_path / "k.npz", p)
-    assert back.mask_seed == sk.mask_seed and np.array_equal(back.bsk_body, sk.bsk_body)
+    assert np.array_equal(back.mask_seed, sk.mask_seed) and np.array_equal(back.bsk_body, sk.bsk_body)
     with pytest.raises(ValueError):
         ServerKeys(p, keys.ksk, keys.bsk, keys.pfpksk).compress()         # foreign keys carry no mask seed
 

@@ -30,7 +30,7 @@ SIGNATURES = {
     "fheaes_key_words": (_c.c_size_t, [_ctx, _c.c_int]),
     "fheaes_upload_keys": (_c.c_int, [_ctx, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int]),
     "fheaes_key_body_words": (_c.c_size_t, [_ctx, _c.c_int]),
-    "fheaes_upload_keys_seeded": (_c.c_int, [_ctx, _c.c_uint64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int]),
+    "fheaes_upload_keys_seeded": (_c.c_int, [_ctx, _c.POINTER(_c.c_uint32), _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int]),
     "fheaes_set_stream": (_c.c_int, [_ctx, _c.c_void_p]),
     "fheaes_synchronize": (_c.c_int, [_ctx]),
     "fheaes_reserve": (_c.c_int, [_ctx, _c.c_uint64]),
@@ -154,14 +154,15 @@ class Engine:
                 raise ValueError("key %d has %d words, expected %d" % (which, n, self.key_words(which)))
         self._check(self._lib.fheaes_upload_keys(self._h, _ptr(ksk)[0], _ptr(bsk)[0], _ptr(pfpksk)[0], sp))
 
-    def upload_keys_seeded(self, mask_seed: int, ksk_body, bsk_body, pfpksk_body):
-        """keys as (public mask seed, bodies): masks are regenerated on the GPU (include/fheaes.h)"""
+    def upload_keys_seeded(self, mask_key, ksk_body, bsk_body, pfpksk_body):
+        """keys as (public 256-bit mask key = 8 uint32, bodies): masks are regenerated on the GPU (include/fheaes.h)"""
+        mk = np.ascontiguousarray(np.asarray(mask_key, dtype=np.uint32).reshape(8))
         sp = self._space(ksk_body, bsk_body, pfpksk_body)
         for which, a in enumerate((ksk_body, bsk_body, pfpksk_body)):
             n = a.size if isinstance(a, np.ndarray) else a.numel()
             if n != self._lib.fheaes_key_body_words(self._h, which):
                 raise ValueError("key body %d has %d words, expected %d" % (which, n, self._lib.fheaes_key_body_words(self._h, which)))
-        self._check(self._lib.fheaes_upload_keys_seeded(self._h, int(mask_seed) & (2 ** 64 - 1), _ptr(ksk_body)[0], _ptr(bsk_body)[0],
+        self._check(self._lib.fheaes_upload_keys_seeded(self._h, mk.ctypes.data_as(_c.POINTER(_c.c_uint32)), _ptr(ksk_body)[0], _ptr(bsk_body)[0],
                                                         _ptr(pfpksk_body)[0], sp))
 
     def set_stream(self, stream_handle: int | None):

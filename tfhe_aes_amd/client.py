@@ -30,13 +30,16 @@ def _load():
         u8p = ctypes.POINTER(ctypes.c_uint8)
         u64p = ctypes.POINTER(ctypes.c_uint64)
         pp = ctypes.POINTER(CParams)
-        lib.fheaes_client_gen_secret_keys.argtypes = [pp, ctypes.c_uint64, u8p, u8p]
-        lib.fheaes_client_gen_ksk.argtypes = [pp, ctypes.c_uint64, ctypes.c_uint64, u8p, u8p, ctypes.c_double, u64p]
-        lib.fheaes_client_gen_bsk.argtypes = [pp, ctypes.c_uint64, ctypes.c_uint64, u8p, u8p, ctypes.c_double, u64p]
-        lib.fheaes_client_gen_pfpksk.argtypes = [pp, ctypes.c_uint64, ctypes.c_uint64, u8p, ctypes.c_double, u64p]
-        lib.fheaes_client_mask_word.argtypes = [ctypes.c_uint64] * 4
+        u32p = ctypes.POINTER(ctypes.c_uint32)
+        lib.fheaes_client_gen_secret_keys.argtypes = [pp, u32p, u8p, u8p]
+        lib.fheaes_client_gen_ksk.argtypes = [pp, u32p, u32p, u8p, u8p, ctypes.c_double, u64p]
+        lib.fheaes_client_gen_bsk.argtypes = [pp, u32p, u32p, u8p, u8p, ctypes.c_double, u64p]
+        lib.fheaes_client_gen_pfpksk.argtypes = [pp, u32p, u32p, u8p, ctypes.c_double, u64p]
+        lib.fheaes_client_mask_word.argtypes = [u32p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64]
         lib.fheaes_client_mask_word.restype = ctypes.c_uint64
-        lib.fheaes_client_encrypt_bits.argtypes = [pp, ctypes.c_uint64, u8p, ctypes.c_double, u8p, ctypes.c_uint64, u64p]
+        lib.fheaes_client_chacha20_block.argtypes = [u32p, ctypes.c_uint32, u32p, u32p]
+        lib.fheaes_client_chacha20_block.restype = None
+        lib.fheaes_client_encrypt_bits.argtypes = [pp, u32p, u8p, ctypes.c_double, u8p, ctypes.c_uint64, u64p]
         lib.fheaes_client_decrypt_bits.argtypes = [pp, u8p, u64p, ctypes.c_uint64, u8p, u64p]
         lib.fheaes_client_phase_small.argtypes = [pp, u8p, u64p, ctypes.c_uint64, u64p]
         lib.fheaes_client_glwe_phase.argtypes = [pp, u8p, u64p, ctypes.c_uint64, u64p]
@@ -56,25 +59,63 @@ def _u64(a):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
 
 
-MASK_TAG_KSK, MASK_TAG_BSK, MASK_TAG_PFPKSK = 3, 4, 5          # csrc/client.c, csrc/engine.hip
-_M64 = (1 << 64) - 1
+def _u32(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
 
 
-def _mix64(z):
-    """splitmix64 finaliser on numpy uint64 arrays (wrapping arithmetic)"""
-    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-    return z ^ (z >> np.uint64(31))
+def random_key() -> np.ndarray:
+    """a fresh 256-bit ChaCha20 key from the OS"""
+    return np.frombuffer(os.urandom(32), dtype=np.uint32).copy()
 
 
-def mask_words(mask_seed: int, tag: int, n_cts: int, words_per_ct: int) -> np.ndarray:
-    """The public mask stream of csrc/client.c in numpy: [n_cts][words_per_ct] uint64.  Host-side twin of the
-    engine's expansion kernel (tests compare both with the masks inside the full keys)."""
+def test_key(seed: int, purpose: int, counter: int = 0) -> np.ndarray:
+    """TEST-ONLY deterministic 256-bit key: (seed, "test", purpose, counter) -- 64 bits of entropy at most"""
+    seed &= (1 << 64) - 1
+    return np.array([seed & 0xFFFFFFFF, seed >> 32, 0x74736574, purpose & 0xFFFFFFFF, counter & 0xFFFFFFFF, (counter >> 32) & 0xFFFFFFFF, 0, 0], dtype=np.uint32)
+
+
+MASK_TAG_KSK, MASK_TAG_BSK, MASK_TAG_PFPKSK = 3, 4, 5          # csrc/client.c, csrc/kern_linear.h
+
+
+def chacha20_blocks(key8: np.ndarray, counters: np.ndarray, nonce0: int, nonce1: np.ndarray, nonce2: np.ndarray) -> np.ndarray:
+    """RFC 8439 block function, vectorised: one block per entry of `counters` / `nonce1` / `nonce2` (broadcast together);
+    returns uint32 [..., 16].  The host-side twin of csrc/client.c::chacha20_block and kern_linear.h::fheaes_chacha20_block."""
+    counters, nonce1, nonce2 = np.broadcast_arrays(np.asarray(counters, dtype=np.uint32), np.asarray(nonce1, dtype=np.uint32),
+                                                   np.asarray(nonce2, dtype=np.uint32))
+    shape = counters.shape
+    init = [np.full(shape, c, dtype=np.uint32) for c in (0x61707865, 0x3320646E, 0x79622D32, 0x6B206574)]
+    init += [np.full(shape, int(k), dtype=np.uint32) for k in np.asarray(key8, dtype=np.uint32)]
+    init += [counters.copy(), np.full(shape, nonce0 & 0xFFFFFFFF, dtype=np.uint32), nonce1.copy(), nonce2.copy()]
+    x = [v.copy() for v in init]
+
+    def rotl(v, k):
+        return (v << np.uint32(k)) | (v >> np.uint32(32 - k))
+
+    def qr(a, b, c, d):
+        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7)
+
     with np.errstate(over="ignore"):
-        ct = np.arange(n_cts, dtype=np.uint64)
-        base = _mix64(np.uint64(mask_seed & _M64) ^ np.uint64((tag * 0xD6E8FEB86659FD93) & _M64) ^ (ct * np.uint64(0xA24BAED4963EE407)))
-        j = np.arange(1, words_per_ct + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
-        return _mix64(base[:, None] + j[None, :])
+        for _ in range(10):
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+        return np.stack([x[i] + init[i] for i in range(16)], axis=-1)
+
+
+def mask_words(mask_key: np.ndarray, tag: int, n_cts: int, words_per_ct: int) -> np.ndarray:
+    """The public mask stream of csrc/client.c in numpy: [n_cts][words_per_ct] uint64 -- 64-bit word j % 8 of ChaCha20 block
+    j / 8 under (mask key, nonce = (tag, ct)).  Host-side twin of the engine's expansion kernel."""
+    blocks = (words_per_ct + 7) // 8
+    out = np.empty((n_cts, blocks * 8), dtype=np.uint64)
+    step = max(1, (1 << 21) // blocks)                                     # bound the temporaries
+    for c0 in range(0, n_cts, step):
+        ct = np.arange(c0, min(n_cts, c0 + step), dtype=np.uint64)
+        w = chacha20_blocks(mask_key, np.arange(blocks, dtype=np.uint32)[None, :], tag, (ct & np.uint64(0xFFFFFFFF)).astype(np.uint32)[:, None],
+                            (ct >> np.uint64(32)).astype(np.uint32)[:, None])      # [cts][blocks][16]
+        out[c0:c0 + len(ct)] = np.ascontiguousarray(w).view(np.uint64).reshape(len(ct), blocks * 8)
+    return out[:, :words_per_ct]
 
 
 @dataclass
@@ -83,14 +124,14 @@ class SeededServerKeys:
     ``fheaes_upload_keys_seeded``, on the host by ``expand()``), so 0.19 GB travel instead of 1.04 GB at PARAM_OPT.
     Bodies: KSK [kN][ks_level] words; BSK [n][pbs_level][k+1][N]; PFPKSK [k+1][kN+1][pfks_level][N]."""
     params: WopbsParameters
-    mask_seed: int
+    mask_seed: np.ndarray          # the PUBLIC 256-bit mask key, uint32[8]
     ksk_body: np.ndarray
     bsk_body: np.ndarray
     pfpksk_body: np.ndarray
 
     @property
     def nbytes(self) -> int:
-        return 8 + self.ksk_body.nbytes + self.bsk_body.nbytes + self.pfpksk_body.nbytes
+        return 32 + self.ksk_body.nbytes + self.bsk_body.nbytes + self.pfpksk_body.nbytes
 
     def expand(self) -> "ServerKeys":
         p = self.params
@@ -109,7 +150,7 @@ class SeededServerKeys:
         return ServerKeys(p, ksk.reshape(-1), bsk.reshape(-1), pf.reshape(-1), mask_seed=self.mask_seed)
 
     def save(self, path) -> None:
-        np.savez(path, shape=_param_shape(self.params), mask_seed=np.array([self.mask_seed], dtype=np.uint64),
+        np.savez(path, shape=_param_shape(self.params), mask_seed=np.asarray(self.mask_seed, dtype=np.uint32),
                  ksk_body=self.ksk_body, bsk_body=self.bsk_body, pfpksk_body=self.pfpksk_body)
 
     @staticmethod
@@ -117,11 +158,11 @@ class SeededServerKeys:
         with np.load(path, allow_pickle=False) as z:
             if list(map(int, z["shape"])) != list(map(int, _param_shape(params))):
                 raise ValueError("key file was generated for a different parameter set")
-            out = SeededServerKeys(params, int(z["mask_seed"][0]), z["ksk_body"].astype(np.uint64), z["bsk_body"].astype(np.uint64),
+            out = SeededServerKeys(params, z["mask_seed"].astype(np.uint32), z["ksk_body"].astype(np.uint64), z["bsk_body"].astype(np.uint64),
                                    z["pfpksk_body"].astype(np.uint64))
         k, N = params.k, params.N
         want = (params.big * params.ks_level, params.n * params.pbs_level * (k + 1) * N, (k + 1) * params.big1 * params.pfks_level * N)
-        if (out.ksk_body.size, out.bsk_body.size, out.pfpksk_body.size) != want:
+        if (out.ksk_body.size, out.bsk_body.size, out.pfpksk_body.size) != want or out.mask_seed.size != 8:
             raise ValueError("key file has the wrong array sizes")
         return out
 
@@ -139,7 +180,7 @@ class ServerKeys:
     ksk: np.ndarray      # [kN][ks_level][n+1]
     bsk: np.ndarray      # [n][pbs_level][k+1][k+1][N]   standard domain
     pfpksk: np.ndarray   # [k+1][kN+1][pfks_level][(k+1)N]
-    mask_seed: int | None = None   # set when the masks follow the public stream of csrc/client.c (keys made by Client)
+    mask_seed: np.ndarray | None = None   # the public 256-bit mask key when the masks follow the stream of csrc/client.c (keys made by Client)
 
     def compress(self) -> "SeededServerKeys":
         """(mask_seed, bodies): drops every mask word (they are a function of the public mask seed)"""
@@ -185,13 +226,12 @@ def bytes_to_u128(b) -> int:
 class Client:
     """``Client::new`` (client.rs:70): generates the secret and evaluation keys.
 
-    ``seed=None`` (the default, the counterpart of the reference's OS-seeded generators, client.rs:106-107): the key
-    seed and the seed of every encryption call are drawn from ``os.urandom``.  An explicit integer ``seed`` is the
-    TEST-ONLY deterministic mode (golden vectors, parity tests, synthetic bench data): keys derive from it and
-    encryption call i uses ``seed + 0x1000 * i`` -- two processes with the same seed then reuse masks and noise,
-    which is exactly what reproducible fixtures need and what real use must never do.  Either way the generator
-    is xoshiro256** (csrc/client.c), not a CSPRNG: this Client makes synthetic inputs for the engine, it is not a
-    hardened replacement of tfhe-rs key generation."""
+    All randomness is ChaCha20 (csrc/client.c).  ``seed=None`` (the default, the counterpart of the reference's OS-seeded
+    generators, client.rs:106-107): the 256-bit secret key-generation key, the 256-bit PUBLIC mask key and a fresh 256-bit key
+    for every encryption call come from ``os.urandom``.  An explicit integer ``seed`` is the TEST-ONLY deterministic mode
+    (golden vectors, parity tests, synthetic bench data): all keys derive from that one number (at most 64 bits of entropy)
+    and encryption call i is reproducible -- two processes with the same seed then produce the same masks and noise, which
+    is exactly what fixtures need and what real use must never do."""
 
     def __init__(self, number_of_outputs: int = 1, iv: int = 0, key: int = 0,
                  params: WopbsParameters = PARAM_OPT, seed: int | None = None):
@@ -200,16 +240,15 @@ class Client:
         self.iv = iv
         self.key = key
         self.deterministic = seed is not None
-        self.seed = int(seed) & (2 ** 64 - 1) if seed is not None else int.from_bytes(os.urandom(8), "little")
-        # PUBLIC seed of the evaluation keys' mask words (it travels with the compressed keys); independent of the
-        # secret seed unless the deterministic test mode derives both from one number
-        self.mask_seed = (self.seed * 0x9E3779B97F4A7C15 + 0xA5A5A5A5) & (2 ** 64 - 1) if seed is not None else int.from_bytes(os.urandom(8), "little")
+        self.test_seed = int(seed) if seed is not None else None
+        self.seed = test_key(self.test_seed, 1) if self.deterministic else random_key()          # SECRET
+        self.mask_seed = test_key(self.test_seed, 2) if self.deterministic else random_key()     # PUBLIC: travels with seeded keys
         self._enc_counter = 0
         lib = _load()
         self._c = params.c_struct()
         self.lwe_sk = np.zeros(params.n, dtype=np.uint8)
         self.glwe_sk = np.zeros(params.big, dtype=np.uint8)
-        lib.fheaes_client_gen_secret_keys(ctypes.byref(self._c), seed, _u8(self.lwe_sk), _u8(self.glwe_sk))
+        lib.fheaes_client_gen_secret_keys(ctypes.byref(self._c), _u32(self.seed), _u8(self.lwe_sk), _u8(self.glwe_sk))
         self._server_keys = None
 
     # -- keys -----------------------------------------------------------------
@@ -220,11 +259,12 @@ class Client:
             ksk = np.empty(p.ksk_words, dtype=np.uint64)
             bsk = np.empty(p.bsk_words, dtype=np.uint64)
             pf = np.empty(p.pfpksk_words, dtype=np.uint64)
-            lib.fheaes_client_gen_ksk(ctypes.byref(self._c), self.seed, self.mask_seed, _u8(self.lwe_sk), _u8(self.glwe_sk),
+            lib.fheaes_client_gen_ksk(ctypes.byref(self._c), _u32(self.seed), _u32(self.mask_seed), _u8(self.lwe_sk), _u8(self.glwe_sk),
                                       p.lwe_noise_std, _u64(ksk))
-            lib.fheaes_client_gen_bsk(ctypes.byref(self._c), self.seed, self.mask_seed, _u8(self.lwe_sk), _u8(self.glwe_sk),
+            lib.fheaes_client_gen_bsk(ctypes.byref(self._c), _u32(self.seed), _u32(self.mask_seed), _u8(self.lwe_sk), _u8(self.glwe_sk),
                                       p.glwe_noise_std, _u64(bsk))
-            lib.fheaes_client_gen_pfpksk(ctypes.byref(self._c), self.seed, self.mask_seed, _u8(self.glwe_sk), p.pfks_noise_std, _u64(pf))
+            lib.fheaes_client_gen_pfpksk(ctypes.byref(self._c), _u32(self.seed), _u32(self.mask_seed), _u8(self.glwe_sk), p.pfks_noise_std,
+                                         _u64(pf))
             self._server_keys = ServerKeys(p, ksk, bsk, pf, mask_seed=self.mask_seed)
         return self._server_keys
 
@@ -234,8 +274,8 @@ class Client:
         bits = np.ascontiguousarray(bits, dtype=np.uint8)
         out = np.empty(bits.shape + (self.params.big1,), dtype=np.uint64)
         self._enc_counter += 1
-        enc_seed = (self.seed + 0x1000 * self._enc_counter) & (2 ** 64 - 1) if self.deterministic else int.from_bytes(os.urandom(8), "little")
-        _load().fheaes_client_encrypt_bits(ctypes.byref(self._c), enc_seed, _u8(self.glwe_sk),
+        enc_key = test_key(self.test_seed, 3, self._enc_counter) if self.deterministic else random_key()
+        _load().fheaes_client_encrypt_bits(ctypes.byref(self._c), _u32(enc_key), _u8(self.glwe_sk),
                                            self.params.glwe_noise_std, _u8(bits), bits.size, _u64(out))
         return out
 

@@ -16,16 +16,17 @@
  *          sigma_i = S_flat[i] (i<kN), sigma_kN = -1;  f_r(x) = -x*S_r(X) (r<k), f_k(x) = x
  * 
  *
- * Randomness.  Two independent inputs:
- *   seed       SECRET: secret keys and every noise sample (xoshiro256** seeded per key ciphertext from
- *              (seed, tag, index) through splitmix64, so the output does not depend on the thread count;
- *              Gaussian noise by the Marsaglia polar method with a series logarithm: + - * / sqrt only, no libm
- *              dependence, bit-reproducible);
- *   mask_seed  PUBLIC: every mask word of the evaluation keys.  Mask word j of key ciphertext q of key `tag` is the
- *              j-th output of the splitmix64 sequence started at mix(mask_seed, tag, q) -- a counter-based stream with
- *              random access, so the engine can regenerate all masks on the GPU from (mask_seed, bodies):
- *              fheaes_upload_keys_seeded ships 0.19 GB instead of 1.04 GB (include/fheaes.h).
- * Synthetic-data quality, not a CSPRNG.
+ * Randomness: ChaCha20 (RFC 8439 block function, 20 rounds) under two independent 256-bit keys:
+ *   secret key  secret keys and every noise sample: one stream per key ciphertext / encryption, nonce = (tag, index),
+ *               so the output does not depend on the thread count; Gaussian noise by the Marsaglia polar method with a
+ *               series logarithm (+ - * / sqrt only: no libm dependence, bit-reproducible);
+ *   mask key    PUBLIC: every mask word of the evaluation keys.  Mask word j of key ciphertext q of key `tag` is 64-bit
+ *               word j % 8 of ChaCha20 block j / 8 under (mask key, nonce = (tag, q)): counter-based, random access, so
+ *               the engine regenerates all masks on the GPU from (mask key, bodies): fheaes_upload_keys_seeded ships
+ *               0.19 GB instead of 1.04 GB (include/fheaes.h).  This is the role tfhe-csprng's public seeds play for
+ *               tfhe-rs' Seeded* containers (different generator: theirs is AES-CTR; streams are not interchangeable).
+ * The Python Client draws both keys, and a fresh key per encryption call, from os.urandom unless it is given an explicit
+ * test seed (client.py).
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -35,48 +36,69 @@
 
 #define NPOLY 512
 
-/* ---------------------------------------------------------------- PRNG */
-typedef struct { uint64_t s[4]; } rng_t;
-
-static inline uint64_t splitmix64(uint64_t *x)
-{
-    uint64_t z = (*x += 0x9E3779B97F4A7C15ULL);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
-
-static void rng_seed(rng_t *r, uint64_t seed, uint64_t tag, uint64_t row)
-{
-    uint64_t x = seed ^ (tag * 0xD6E8FEB86659FD93ULL) ^ (row * 0xA24BAED4963EE407ULL);
-    for (int i = 0; i < 4; ++i) r->s[i] = splitmix64(&x);
-}
-
-/* ---- the public mask stream (must stay identical to fheaes_mask_word in csrc/engine.hip) ---- */
+/* ---------------------------------------------------------------- PRNG: ChaCha20 */
 #define MASK_TAG_KSK 3
 #define MASK_TAG_BSK 4
 #define MASK_TAG_PFPKSK 5
-static inline uint64_t mix64(uint64_t z)
-{
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
-static inline uint64_t mask_base(uint64_t mask_seed, uint64_t tag, uint64_t ct)
-{
-    return mix64(mask_seed ^ (tag * 0xD6E8FEB86659FD93ULL) ^ (ct * 0xA24BAED4963EE407ULL));
-}
-static inline uint64_t mask_word(uint64_t base, uint64_t j) { return mix64(base + (j + 1) * 0x9E3779B97F4A7C15ULL); }
-uint64_t fheaes_client_mask_word(uint64_t mask_seed, uint64_t tag, uint64_t ct, uint64_t j) { return mask_word(mask_base(mask_seed, tag, ct), j); }
 
-static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+#define CHACHA_QR(a, b, c, d) \
+    a += b; d ^= a; d = rotl32(d, 16); c += d; b ^= c; b = rotl32(b, 12); \
+    a += b; d ^= a; d = rotl32(d, 8);  c += d; b ^= c; b = rotl32(b, 7)
+
+/* RFC 8439 section 2.3: state = "expand 32-byte k" | key[8] | counter | nonce[3]; out = 16 words (must stay identical to
+ * fheaes_chacha20_block in csrc/kern_linear.h and to client.chacha20_blocks in client.py) */
+static void chacha20_block(const uint32_t key[8], uint32_t counter, const uint32_t nonce[3], uint32_t out[16])
+{
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                      key[4], key[5], key[6], key[7], counter, nonce[0], nonce[1], nonce[2]};
+    uint32_t x[16];
+    memcpy(x, s, sizeof x);
+    for (int r = 0; r < 10; ++r) {
+        CHACHA_QR(x[0], x[4], x[8], x[12]); CHACHA_QR(x[1], x[5], x[9], x[13]);
+        CHACHA_QR(x[2], x[6], x[10], x[14]); CHACHA_QR(x[3], x[7], x[11], x[15]);
+        CHACHA_QR(x[0], x[5], x[10], x[15]); CHACHA_QR(x[1], x[6], x[11], x[12]);
+        CHACHA_QR(x[2], x[7], x[8], x[13]); CHACHA_QR(x[3], x[4], x[9], x[14]);
+    }
+    for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];
+}
+void fheaes_client_chacha20_block(const uint32_t *key8, uint32_t counter, const uint32_t *nonce3, uint32_t *out16) { chacha20_block(key8, counter, nonce3, out16); }
+
+/* one sequential stream: (key, tag, index) */
+typedef struct { uint32_t key[8], nonce[3], counter, buf[16]; int pos; } rng_t;
+
+static void rng_seed(rng_t *r, const uint32_t *key8, uint64_t tag, uint64_t index)
+{
+    memcpy(r->key, key8, 32);
+    r->nonce[0] = (uint32_t)tag; r->nonce[1] = (uint32_t)index; r->nonce[2] = (uint32_t)(index >> 32);
+    r->counter = 0; r->pos = 16;
+}
 
 static inline uint64_t rng_next(rng_t *r)
 {
-    uint64_t *s = r->s;
-    uint64_t result = rotl64(s[1] * 5, 7) * 9, t = s[1] << 17;
-    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl64(s[3], 45);
-    return result;
+    if (r->pos >= 16) { chacha20_block(r->key, r->counter++, r->nonce, r->buf); r->pos = 0; }
+    uint64_t v = (uint64_t)r->buf[r->pos] | ((uint64_t)r->buf[r->pos + 1] << 32);
+    r->pos += 2;
+    return v;
+}
+
+/* ---- the public mask stream: random access, 8 words per block ---- */
+typedef struct { const uint32_t *key; uint32_t nonce[3]; uint32_t buf[16]; uint32_t have; } mask_t;
+static void mask_seed_ct(mask_t *m, const uint32_t *mask_key8, uint64_t tag, uint64_t ct)
+{
+    m->key = mask_key8; m->nonce[0] = (uint32_t)tag; m->nonce[1] = (uint32_t)ct; m->nonce[2] = (uint32_t)(ct >> 32); m->have = 0xFFFFFFFFu;
+}
+static inline uint64_t mask_word(mask_t *m, uint64_t j)
+{
+    const uint32_t blk = (uint32_t)(j >> 3), w = (uint32_t)(j & 7);
+    if (m->have != blk) { chacha20_block(m->key, blk, m->nonce, m->buf); m->have = blk; }
+    return (uint64_t)m->buf[2 * w] | ((uint64_t)m->buf[2 * w + 1] << 32);
+}
+uint64_t fheaes_client_mask_word(const uint32_t *mask_key8, uint64_t tag, uint64_t ct, uint64_t j)
+{
+    mask_t m;
+    mask_seed_ct(&m, mask_key8, tag, ct);
+    return mask_word(&m, j);
 }
 
 /* ln(x) for x in (0,1], by exponent split + atanh series; deterministic IEEE ops only */
@@ -126,17 +148,17 @@ static int build_positions(const uint8_t *bits, int *pos)
     return c;
 }
 
-/* fresh GLWE_S(0): mask = public stream `mbase`, body = sum A_m S_m + e (noise from the secret stream r) */
-static void glwe_encrypt_zero(rng_t *r, uint64_t mbase, int k, const int *pos, const int *npos, double sigma, uint64_t *ct)
+/* fresh GLWE_S(0): mask = public stream `m`, body = sum A_m S_m + e (noise from the secret stream r) */
+static void glwe_encrypt_zero(rng_t *r, mask_t *m, int k, const int *pos, const int *npos, double sigma, uint64_t *ct)
 {
     uint64_t *body = ct + (size_t)k * NPOLY;
-    for (int j = 0; j < k * NPOLY; ++j) ct[j] = mask_word(mbase, (uint64_t)j);
+    for (int j = 0; j < k * NPOLY; ++j) ct[j] = mask_word(m, (uint64_t)j);
     for (int j = 0; j < NPOLY; ++j) body[j] = noise_word(r, sigma);
     for (int m = 0; m < k; ++m) nega_mac_binary(ct + (size_t)m * NPOLY, pos + (size_t)m * NPOLY, npos[m], body);
 }
 
 /* ---------------------------------------------------------------- API */
-void fheaes_client_gen_secret_keys(const fheaes_params *p, uint64_t seed, uint8_t *lwe_sk /*[n]*/, uint8_t *glwe_sk /*[k*N]*/)
+void fheaes_client_gen_secret_keys(const fheaes_params *p, const uint32_t *seed /*[8]*/, uint8_t *lwe_sk /*[n]*/, uint8_t *glwe_sk /*[k*N]*/)
 {
     rng_t r;
     rng_seed(&r, seed, 1, 0);
@@ -145,7 +167,7 @@ void fheaes_client_gen_secret_keys(const fheaes_params *p, uint64_t seed, uint8_
     for (uint32_t i = 0; i < p->glwe_dimension * NPOLY; ++i) glwe_sk[i] = (uint8_t)(rng_next(&r) >> 63);
 }
 
-void fheaes_client_gen_ksk(const fheaes_params *p, uint64_t seed, uint64_t mask_seed, const uint8_t *lwe_sk, const uint8_t *glwe_sk,
+void fheaes_client_gen_ksk(const fheaes_params *p, const uint32_t *seed, const uint32_t *mask_seed, const uint8_t *lwe_sk, const uint8_t *glwe_sk,
                            double sigma_lwe, uint64_t *ksk)
 {
     int n = (int)p->lwe_dimension, big = (int)(p->glwe_dimension * NPOLY), L = (int)p->ks_level, b = (int)p->ks_base_log;
@@ -155,16 +177,17 @@ void fheaes_client_gen_ksk(const fheaes_params *p, uint64_t seed, uint64_t mask_
         rng_seed(&r, seed, 3, (uint64_t)i);
         for (int l = 0; l < L; ++l) {
             uint64_t *row = ksk + ((size_t)i * L + l) * (n + 1);
-            const uint64_t mb = mask_base(mask_seed, MASK_TAG_KSK, (uint64_t)i * L + l);
+            mask_t mk;
+            mask_seed_ct(&mk, mask_seed, MASK_TAG_KSK, (uint64_t)i * L + l);
             uint64_t body = noise_word(&r, sigma_lwe);
-            for (int j = 0; j < n; ++j) { row[j] = mask_word(mb, (uint64_t)j); if (lwe_sk[j]) body += row[j]; }
+            for (int j = 0; j < n; ++j) { row[j] = mask_word(&mk, (uint64_t)j); if (lwe_sk[j]) body += row[j]; }
             if (glwe_sk[i]) body += 1ULL << (64 - b * (l + 1));
             row[n] = body;
         }
     }
 }
 
-void fheaes_client_gen_bsk(const fheaes_params *p, uint64_t seed, uint64_t mask_seed, const uint8_t *lwe_sk, const uint8_t *glwe_sk,
+void fheaes_client_gen_bsk(const fheaes_params *p, const uint32_t *seed, const uint32_t *mask_seed, const uint8_t *lwe_sk, const uint8_t *glwe_sk,
                            double sigma_glwe, uint64_t *bsk)
 {
     int n = (int)p->lwe_dimension, k = (int)p->glwe_dimension, k1 = k + 1, L = (int)p->pbs_level, b = (int)p->pbs_base_log;
@@ -179,7 +202,9 @@ void fheaes_client_gen_bsk(const fheaes_params *p, uint64_t seed, uint64_t mask_
         for (int l = 0; l < L; ++l) for (int rr = 0; rr < k1; ++rr) {
             const size_t q = ((size_t)i * L + l) * k1 + rr;
             uint64_t *ct = bsk + q * gsz;
-            glwe_encrypt_zero(&r, mask_base(mask_seed, MASK_TAG_BSK, (uint64_t)q), k, pos, npos, sigma_glwe, ct);
+            mask_t mk;
+            mask_seed_ct(&mk, mask_seed, MASK_TAG_BSK, (uint64_t)q);
+            glwe_encrypt_zero(&r, &mk, k, pos, npos, sigma_glwe, ct);
             if (!lwe_sk[i]) continue;
             /* row (l, r) carries s_i * g_l on component r.  The message goes into the BODY (row r < k: -g_l * S_r(X),
              * row k: +g_l), never into a mask polynomial: same phase as adding g_l to mask coefficient 0 of polynomial r,
@@ -193,7 +218,7 @@ void fheaes_client_gen_bsk(const fheaes_params *p, uint64_t seed, uint64_t mask_
     free(pos);
 }
 
-void fheaes_client_gen_pfpksk(const fheaes_params *p, uint64_t seed, uint64_t mask_seed, const uint8_t *glwe_sk, double sigma_pfks, uint64_t *pfpksk)
+void fheaes_client_gen_pfpksk(const fheaes_params *p, const uint32_t *seed, const uint32_t *mask_seed, const uint8_t *glwe_sk, double sigma_pfks, uint64_t *pfpksk)
 {
     int k = (int)p->glwe_dimension, k1 = k + 1, L = (int)p->pfks_level, b = (int)p->pfks_base_log;
     int big = k * NPOLY, big1 = big + 1;
@@ -211,7 +236,9 @@ void fheaes_client_gen_pfpksk(const fheaes_params *p, uint64_t seed, uint64_t ma
             const size_t q = ((size_t)rr * big1 + i) * L + l;
             uint64_t *ct = pfpksk + q * gsz;
             uint64_t *body = ct + (size_t)k * NPOLY;
-            glwe_encrypt_zero(&r, mask_base(mask_seed, MASK_TAG_PFPKSK, (uint64_t)q), k, pos, npos, sigma_pfks, ct);
+            mask_t mk;
+            mask_seed_ct(&mk, mask_seed, MASK_TAG_PFPKSK, (uint64_t)q);
+            glwe_encrypt_zero(&r, &mk, k, pos, npos, sigma_pfks, ct);
             if (sig == 0) continue;
             uint64_t g = 1ULL << (64 - b * (l + 1));
             uint64_t x = (sig > 0) ? g : (uint64_t)0 - g;            /* sigma_i * g_l */
@@ -223,7 +250,7 @@ void fheaes_client_gen_pfpksk(const fheaes_params *p, uint64_t seed, uint64_t ma
 }
 
 /* encrypt_without_padding (client.rs:128): `count` bits -> LWE under the big key, bit at the MSB */
-void fheaes_client_encrypt_bits(const fheaes_params *p, uint64_t seed, const uint8_t *glwe_sk, double sigma,
+void fheaes_client_encrypt_bits(const fheaes_params *p, const uint32_t *seed /*[8]: one fresh key per call*/, const uint8_t *glwe_sk, double sigma,
                                 const uint8_t *bits, uint64_t count, uint64_t *lwe_out)
 {
     int big = (int)(p->glwe_dimension * NPOLY);

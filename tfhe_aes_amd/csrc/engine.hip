@@ -741,8 +741,9 @@ int fheaes_reserve(fheaes_ctx *c, uint64_t max_bits)
 
 // Both uploads end in the same three conversions of the standard-domain words staged in HBM: KSK / PFPKSK -> balanced int8
 // byte planes in MFMA fragment order, BSK -> Fourier.  `seeded`: the caller passed bodies only and the masks are
-// regenerated on the GPU from the public mask seed (csrc/client.c) -- 0.19 GB over PCIe / xGMI instead of 1.04 GB.
-static int upload_keys_impl(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, const uint64_t *pfpksk, int memspace, bool seeded, uint64_t mask_seed)
+// regenerated on the GPU from the public 256-bit mask key (ChaCha20 stream of csrc/client.c) -- 0.19 GB over PCIe / xGMI
+// instead of 1.04 GB.
+static int upload_keys_impl(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, const uint64_t *pfpksk, int memspace, bool seeded, const MaskKey &mask_key)
 {
     if (!c || !ksk || !bsk || !pfpksk) return c ? c->fail(FHEAES_ERR_INVALID, "null key pointer") : FHEAES_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -788,7 +789,7 @@ static int upload_keys_impl(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *
             bodies = (const uint64_t *)tmp_body;
         }
         hipLaunchKernelGGL(expand_masks_kernel, dim3(8192), dim3(256), 0, c->stream, (uint64_t *)tmp, bodies, cts[which], mask_w[which], body_w[which],
-                           mask_seed, tags[which]);
+                           mask_key, (uint32_t)tags[which]);
         return (const uint64_t *)tmp;
     };
     int rc = FHEAES_OK;
@@ -827,12 +828,16 @@ static int upload_keys_impl(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *
 
 int fheaes_upload_keys(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, const uint64_t *pfpksk, int memspace)
 {
-    return upload_keys_impl(c, ksk, bsk, pfpksk, memspace, false, 0);
+    return upload_keys_impl(c, ksk, bsk, pfpksk, memspace, false, MaskKey{});
 }
 
-int fheaes_upload_keys_seeded(fheaes_ctx *c, uint64_t mask_seed, const uint64_t *ksk_body, const uint64_t *bsk_body, const uint64_t *pfpksk_body, int memspace)
+int fheaes_upload_keys_seeded(fheaes_ctx *c, const uint32_t *mask_key, const uint64_t *ksk_body, const uint64_t *bsk_body, const uint64_t *pfpksk_body,
+                              int memspace)
 {
-    return upload_keys_impl(c, ksk_body, bsk_body, pfpksk_body, memspace, true, mask_seed);
+    if (!c || !mask_key) return c ? c->fail(FHEAES_ERR_INVALID, "null mask key") : FHEAES_ERR_INVALID;
+    MaskKey k;
+    memcpy(k.k, mask_key, sizeof k.k);                       // the 32-byte key itself is always a HOST array
+    return upload_keys_impl(c, ksk_body, bsk_body, pfpksk_body, memspace, true, k);
 }
 
 size_t fheaes_key_body_words(const fheaes_ctx *c, int which)

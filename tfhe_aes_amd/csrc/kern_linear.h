@@ -101,29 +101,58 @@ __global__ __launch_bounds__(256) void counter_lut_kernel(uint64_t *luts, const 
 }
 
 // ---- seeded evaluation keys (fheaes_upload_keys_seeded) -------------------------------------------------------------
-// Mask word j of key ciphertext q of key `tag` = the j-th output of the splitmix64 sequence started at
-// mix(mask_seed, tag, q): the public, counter-based stream of csrc/client.c (kept identical here).
-__device__ __host__ __forceinline__ uint64_t fheaes_mix64(uint64_t z)
+// Mask word j of key ciphertext q of key `tag` = 64-bit word j % 8 of ChaCha20 block j / 8 under (public mask key,
+// nonce = (tag, q)): the counter-based stream of csrc/client.c (RFC 8439 block function; kept identical here).
+struct MaskKey {
+    uint32_t k[8];
+};
+
+#define FHEAES_QR(a, b, c, d)                                                   \
+    a += b; d ^= a; d = (d << 16) | (d >> 16); c += d; b ^= c; b = (b << 12) | (b >> 20); \
+    a += b; d ^= a; d = (d << 8) | (d >> 24);  c += d; b ^= c; b = (b << 7) | (b >> 25)
+
+__device__ __forceinline__ void fheaes_chacha20_block(const MaskKey &key, uint32_t counter, uint32_t n0, uint32_t n1, uint32_t n2, uint32_t (&out)[16])
 {
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    return z ^ (z >> 31);
-}
-__device__ __host__ __forceinline__ uint64_t fheaes_mask_word(uint64_t mask_seed, uint64_t tag, uint64_t q, uint64_t j)
-{
-    const uint64_t base = fheaes_mix64(mask_seed ^ (tag * 0xD6E8FEB86659FD93ULL) ^ (q * 0xA24BAED4963EE407ULL));
-    return fheaes_mix64(base + (j + 1) * 0x9E3779B97F4A7C15ULL);
+    const uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3],
+                            key.k[4], key.k[5], key.k[6], key.k[7], counter, n0, n1, n2};
+    uint32_t x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = s[i];
+#pragma unroll 1
+    for (int r = 0; r < 10; ++r) {
+        FHEAES_QR(x[0], x[4], x[8], x[12]); FHEAES_QR(x[1], x[5], x[9], x[13]);
+        FHEAES_QR(x[2], x[6], x[10], x[14]); FHEAES_QR(x[3], x[7], x[11], x[15]);
+        FHEAES_QR(x[0], x[5], x[10], x[15]); FHEAES_QR(x[1], x[6], x[11], x[12]);
+        FHEAES_QR(x[2], x[7], x[8], x[13]); FHEAES_QR(x[3], x[4], x[9], x[14]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[i] = x[i] + s[i];
 }
 
-// out [n_cts][mask_words + body_words] <- regenerated masks | bodies [n_cts][body_words]   (HBM-bound: one 8-byte store per word)
+// out [n_cts][mask_words + body_words] <- regenerated masks | bodies [n_cts][body_words].  One thread per (ciphertext,
+// 8-word block of its mask); the bodies are copied by the threads of the last block(s).
 __global__ __launch_bounds__(256) void expand_masks_kernel(uint64_t *out, const uint64_t *bodies, uint64_t n_cts, uint32_t mask_words,
-                                                           uint32_t body_words, uint64_t mask_seed, uint64_t tag)
+                                                           uint32_t body_words, MaskKey key, uint32_t tag)
 {
     const uint32_t ct_words = mask_words + body_words;
-    const uint64_t total = n_cts * ct_words;
+    const uint32_t mask_blocks = (mask_words + 7) / 8, body_blocks = (body_words + 7) / 8;
+    const uint32_t blocks = mask_blocks + body_blocks;
+    const uint64_t total = n_cts * blocks;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t q = i / ct_words;
-        const uint32_t j = (uint32_t)(i - q * ct_words);
-        out[i] = j < mask_words ? fheaes_mask_word(mask_seed, tag, q, j) : bodies[q * body_words + (j - mask_words)];
+        const uint64_t q = i / blocks;
+        const uint32_t bi = (uint32_t)(i - q * blocks);
+        uint64_t *o = out + q * ct_words;
+        if (bi < mask_blocks) {
+            uint32_t w[16];
+            fheaes_chacha20_block(key, bi, tag, (uint32_t)q, (uint32_t)(q >> 32), w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t j = bi * 8 + e;
+                if (j < mask_words) o[j] = (uint64_t)w[2 * e] | ((uint64_t)w[2 * e + 1] << 32);
+            }
+        } else {
+            const uint32_t b0 = (bi - mask_blocks) * 8;
+            for (uint32_t e = 0; e < 8 && b0 + e < body_words; ++e) o[mask_words + b0 + e] = bodies[q * body_words + b0 + e];
+        }
     }
 }

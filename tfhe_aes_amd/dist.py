@@ -45,10 +45,10 @@ def broadcast_keys(params, keys, device, src: int = 0):
 
 
 def broadcast_keys_seeded(params, seeded, device, src: int = 0):
-    """The same, for keys in their compressed form (client.SeededServerKeys on rank `src`, None elsewhere): the public mask
-    seed and the three body arrays travel (0.19 GB instead of 1.04 GB at PARAM_OPT: one 8-byte and three tensor
+    """The same, for keys in their compressed form (client.SeededServerKeys on rank `src`, None elsewhere): the public 256-bit
+    mask key and the three body arrays travel (0.19 GB instead of 1.04 GB at PARAM_OPT: one 32-byte and three tensor
     broadcasts); every rank regenerates the masks on its own GPU (Engine.upload_keys_seeded).
-    Returns (mask_seed, [ksk_body, bsk_body, pfpksk_body]) with the bodies as int64 tensors on `device`."""
+    Returns (mask_key as uint32[8], [ksk_body, bsk_body, pfpksk_body]) with the bodies as int64 tensors on `device`."""
     import torch
     import torch.distributed as dist
 
@@ -56,11 +56,11 @@ def broadcast_keys_seeded(params, seeded, device, src: int = 0):
     rank = dist.get_rank() if dist.is_initialized() else 0
     k, N = params.k, params.N
     words = (params.big * params.ks_level, params.n * params.pbs_level * (k + 1) * N, (k + 1) * params.big1 * params.pfks_level * N)
-    seed_t = torch.zeros(1, dtype=torch.int64, device=device)
+    seed_t = torch.zeros(8, dtype=torch.int32, device=device)
     if rank == src:
         if seeded is None:
             raise ValueError("the source rank must hold the keys")
-        seed_t[0] = int(np.array([seeded.mask_seed], dtype=np.uint64).view(np.int64)[0])
+        seed_t.copy_(torch.from_numpy(np.asarray(seeded.mask_seed, dtype=np.uint32).reshape(8).view(np.int32).copy()))
         tensors = [torch.from_numpy(np.ascontiguousarray(h).reshape(-1).view(np.int64)).to(device)
                    for h in (seeded.ksk_body, seeded.bsk_body, seeded.pfpksk_body)]
         for t, w in zip(tensors, words):
@@ -72,8 +72,8 @@ def broadcast_keys_seeded(params, seeded, device, src: int = 0):
         dist.broadcast(seed_t, src=src)
         for t in tensors:
             dist.broadcast(t, src=src)
-    mask_seed = int(np.array([int(seed_t.item())], dtype=np.int64).view(np.uint64)[0])
-    return mask_seed, tensors
+    mask_key = seed_t.cpu().numpy().view(np.uint32).copy()
+    return mask_key, tensors
 
 
 def broadcast_tensor(t, src: int = 0):
