@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU to rehearse the N>1 path on a 1-GPU box")
     ap.add_argument("--decrypt", action="store_true", help="time Server::aes_decrypt (BASELINE configs[4] path) instead of aes_encrypt")
+    ap.add_argument("--no-ctr-iteration", action="store_true",
+                    help="skip the extra (untimed-step) measurement of the reference's whole CTR iteration that the default line reports at N=1")
     ap.add_argument("--ctr-add", action="store_true",
                     help="time the reference's whole CTR iteration (main.rs:59-61): Server::add_scalar(iv, i) on the GPU, then aes_encrypt")
     args = ap.parse_args()
@@ -257,6 +259,24 @@ def main():
             dist.all_reduce(v, op=dist.ReduceOp.MIN)
             verified = bool(v.item())
 
+    # ---- the reference's whole CTR iteration (main.rs:59-61: Server::add_scalar(iv, i), then aes_encrypt), one extra step ----
+    ctr_iter = None
+    if rank == 0 and world == 1 and not args.ctr_add and not args.decrypt and not args.no_ctr_iteration:
+        iv_ct = torch.from_numpy(client.encrypt_u128(IV).view(np.int64)).to(dev)
+        st2 = iv_ct.unsqueeze(0).repeat(n_blocks, 1, 1, 1).contiguous()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.add_scalar(st2, n_blocks, list(range(lo, hi)))
+        eng.aes_encrypt(rk, st2, n_blocks)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        ok = all(client.decrypt_u128(st2[i].cpu().numpy().view(np.uint64)) == aes128_encrypt_block(KEY, (IV + lo + i) & ((1 << 128) - 1))
+                 for i in sorted({0, n_blocks // 2, n_blocks - 1}))
+        ctr_iter = {"blocks_per_s": n_blocks / dt, "ms": 1000.0 * dt, "verified_vs_aes": bool(ok),
+                    "note": "one step of %d blocks: Server::add_scalar(encrypted_iv, i) on the GPU (143 bit-CBS per block, 16-step carry chain), "
+                            "then Server::aes_encrypt; the timed `value` uses client-side pre-incremented counters" % n_blocks}
+        del st2
+
     # ---- BASELINE configs[1]: one AES block = 16 S-Box WoPBS in one call (latency, not throughput) ------------
     one_block_ms = None
     if rank == 0:
@@ -315,6 +335,7 @@ def main():
             "verified_vs_aes": verified,
             "config1_one_block_round": {"many_sbox_16_bytes_ms": one_block_ms, "ms_per_sbox": None if one_block_ms is None else one_block_ms / 16.0,
                                         "note": "BASELINE configs[1]: 16 S-Box WoPBS (128 bit-CBS) in one call: latency of the 669-step rotation chain"},
+            "ctr_iteration_with_add_scalar": ctr_iter,
             "stage_ms_per_step": stage_ms,
             "roofline": {
                 "kernel": "blind_rotate16_kernel (blind rotation, K2)", "bound": "valu_f64",

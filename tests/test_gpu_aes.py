@@ -169,6 +169,29 @@ def test_add_scalar_then_encrypt_enqueued_without_sync(toy, toy_server):
     assert np.array_equal(b[0], host[1]) and np.array_equal(b[1], host[0])
 
 
+def test_concurrent_callers_are_serialised(toy, toy_server):
+    """the reference shares one &Server between rayon threads (main.rs:55-61): concurrent calls on one context must not corrupt
+    the workspace (the engine serialises them)"""
+    import threading
+
+    c = toy.client
+    xs = [c.encrypt_bytes([17 * i + 3, 0xF0 ^ i]) for i in range(4)]
+    want = [toy.oracle.wopbs_batch(x, orc.build_lutset(orc.LUTSET_ENC_ROUND)) for x in xs]
+    got = [None] * 4
+
+    def work(i):
+        for _ in range(3):
+            got[i] = toy_server.many_sbox(xs[i], inv=False)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(4):
+        assert np.array_equal(got[i], want[i])
+
+
 def test_many_sbox_param_opt(opt):
     """one AES round's worth of S-Boxes (16 bytes = 128 bit-CBS) at the reference's parameter set"""
     srv = Server(opt.keys, device=0, engine=opt.engine())

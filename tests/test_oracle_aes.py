@@ -117,3 +117,21 @@ def test_server_keys_roundtrip_through_a_file(toy, tmp_path):
     assert np.array_equal(back.ksk, toy.keys.ksk) and np.array_equal(back.bsk, toy.keys.bsk) and np.array_equal(back.pfpksk, toy.keys.pfpksk)
     with pytest.raises(ValueError):
         ServerKeys.load(f, PARAM_OPT)
+
+
+def test_ciphertext_files_round_trip(toy, tmp_path):
+    """on-disk form of encrypted states / round keys (npz of uint64 words, parameter set and kind checked on load)"""
+    from tfhe_aes_amd import PARAM_OPT
+    from tfhe_aes_amd.client import load_ciphertexts, save_ciphertexts
+
+    c, p = toy.client, toy.params
+    st = np.stack([c.encrypt_u128(0x00112233445566778899AABBCCDDEEFF + i) for i in range(2)])
+    save_ciphertexts(tmp_path / "st.npz", p, "state", st)
+    back = load_ciphertexts(tmp_path / "st.npz", p, "state")
+    assert np.array_equal(back, st) and c.decrypt_u128(back[1]) == 0x00112233445566778899AABBCCDDEEFF + 1
+    with pytest.raises(ValueError):
+        load_ciphertexts(tmp_path / "st.npz", p, "round_keys")
+    with pytest.raises(ValueError):
+        load_ciphertexts(tmp_path / "st.npz", PARAM_OPT, "state")
+    with pytest.raises(ValueError):
+        save_ciphertexts(tmp_path / "bad.npz", p, "state", st[:, :8])

@@ -211,6 +211,42 @@ class ServerKeys:
         return keys
 
 
+# ---- ciphertext interchange --------------------------------------------------------------------------------
+# The reference hands whole states across in memory (client_encrypt / client_decrypt_and_verify, client.rs:123-175) and never
+# serialises them.  These helpers give encrypted states and round keys an on-disk / on-wire form so that inputs produced
+# elsewhere can be fed to the engine: a plain .npz of uint64 words (no pickle) in the layout of include/fheaes.h, with the
+# parameter set and the kind recorded and checked on load.
+CIPHERTEXT_KINDS = {
+    "state": (16, 8),           # [blocks][16 bytes][8 bits][kN+1]      Server::aes_encrypt / aes_decrypt / add_scalar
+    "round_keys": (11, 16, 8),  # [11][16][8][kN+1]                     Server::aes_key_expansion output
+    "bytes": (8,),              # [n][8][kN+1]                          sbox / many_sbox inputs
+}
+
+
+def save_ciphertexts(path, params: WopbsParameters, kind: str, words: np.ndarray) -> None:
+    if kind not in CIPHERTEXT_KINDS:
+        raise ValueError("kind must be one of %s" % ", ".join(CIPHERTEXT_KINDS))
+    tail = CIPHERTEXT_KINDS[kind] + (params.big1,)
+    a = np.ascontiguousarray(words, dtype=np.uint64)
+    if a.shape[-len(tail):] != tail:
+        raise ValueError("a %r array must end in shape %r, got %r" % (kind, tail, a.shape))
+    np.savez(path, shape=_param_shape(params), kind=np.frombuffer(kind.encode().ljust(16, b"\0"), dtype=np.uint8), words=a)
+
+
+def load_ciphertexts(path, params: WopbsParameters, kind: str) -> np.ndarray:
+    with np.load(path, allow_pickle=False) as z:
+        if list(map(int, z["shape"])) != list(map(int, _param_shape(params))):
+            raise ValueError("ciphertext file was produced for a different parameter set")
+        got = bytes(z["kind"]).rstrip(b"\0").decode()
+        if got != kind:
+            raise ValueError("ciphertext file holds %r, expected %r" % (got, kind))
+        a = z["words"].astype(np.uint64)
+    tail = CIPHERTEXT_KINDS[kind] + (params.big1,)
+    if a.shape[-len(tail):] != tail:
+        raise ValueError("ciphertext file has the wrong array shape")
+    return a
+
+
 def u128_to_bytes(x: int) -> list[int]:
     """state byte i = bits [8*(15-i), 8*(16-i)) of the u128 (client.rs:126-129)."""
     return [(x >> (8 * (15 - i))) & 0xFF for i in range(16)]

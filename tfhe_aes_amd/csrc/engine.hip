@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -187,6 +188,10 @@ struct fheaes_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err;
+    // The reference shares one `&Server` between rayon worker threads (main.rs:55-61).  A context is one GPU stream and one
+    // workspace, so concurrent calls are made SAFE by serialising them here (batched calls are the way to use the GPU; this
+    // only guarantees that a drop-in that keeps the per-block thread pool does not corrupt the workspace).
+    std::recursive_mutex mu;
     // shapes
     uint32_t n = 0, k = 0, k1 = 0, big = 0, big1 = 0;
     // keys
@@ -238,6 +243,11 @@ struct fheaes_ctx {
         int rc__ = (expr);         \
         if (rc__ != FHEAES_OK) return rc__; \
     } while (0)
+
+struct CtxLock {
+    std::unique_lock<std::recursive_mutex> lk;
+    explicit CtxLock(const fheaes_ctx *c) { if (c) lk = std::unique_lock<std::recursive_mutex>(const_cast<fheaes_ctx *>(c)->mu); }
+};
 
 namespace {
 
@@ -713,6 +723,7 @@ size_t fheaes_key_words(const fheaes_ctx *c, int which)
 
 int fheaes_set_stream(fheaes_ctx *c, void *hip_stream)
 {
+    CtxLock lock__(c);
     if (!c) return FHEAES_ERR_INVALID;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
@@ -721,6 +732,7 @@ int fheaes_set_stream(fheaes_ctx *c, void *hip_stream)
 
 int fheaes_synchronize(fheaes_ctx *c)
 {
+    CtxLock lock__(c);
     if (!c) return FHEAES_ERR_INVALID;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return FHEAES_OK;
@@ -728,6 +740,7 @@ int fheaes_synchronize(fheaes_ctx *c)
 
 int fheaes_reserve(fheaes_ctx *c, uint64_t max_bits)
 {
+    CtxLock lock__(c);
     if (!c) return FHEAES_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     uint64_t bits = std::min<uint64_t>(max_bits, MAX_CHUNK_BITS);
@@ -828,12 +841,14 @@ static int upload_keys_impl(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *
 
 int fheaes_upload_keys(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *bsk, const uint64_t *pfpksk, int memspace)
 {
+    CtxLock lock__(c);
     return upload_keys_impl(c, ksk, bsk, pfpksk, memspace, false, MaskKey{});
 }
 
 int fheaes_upload_keys_seeded(fheaes_ctx *c, const uint32_t *mask_key, const uint64_t *ksk_body, const uint64_t *bsk_body, const uint64_t *pfpksk_body,
                               int memspace)
 {
+    CtxLock lock__(c);
     if (!c || !mask_key) return c ? c->fail(FHEAES_ERR_INVALID, "null mask key") : FHEAES_ERR_INVALID;
     MaskKey k;
     memcpy(k.k, mask_key, sizeof k.k);                       // the 32-byte key itself is always a HOST array
@@ -853,6 +868,7 @@ size_t fheaes_key_body_words(const fheaes_ctx *c, int which)
 
 int fheaes_read_bsk_fourier(fheaes_ctx *c, uint32_t i, double *out)
 {
+    CtxLock lock__(c);
     TRY(check_keys(c));
     if (i >= c->n || !out) return c->fail(FHEAES_ERR_INVALID, "bad GGSW index");
     const size_t words = (size_t)c->p.pbs_level * c->k1 * c->k1 * FHE_N;
@@ -864,6 +880,7 @@ int fheaes_read_bsk_fourier(fheaes_ctx *c, uint32_t i, double *out)
 // ---- stage-by-stage ---------------------------------------------------------------------------
 int fheaes_keyswitch_batch(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t m, uint64_t *lwe_out, int memspace)
 {
+    CtxLock lock__(c);
     TRY(check_keys(c));
     if (!lwe_in || !lwe_out) return c->fail(FHEAES_ERR_INVALID, "null pointer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -878,6 +895,7 @@ int fheaes_keyswitch_batch(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t m, ui
 
 int fheaes_cbs_pbs_batch(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_t level, uint64_t *lwe_out, int memspace)
 {
+    CtxLock lock__(c);
     TRY(check_keys(c));
     if (!lwe_small || !lwe_out) return c->fail(FHEAES_ERR_INVALID, "null pointer");
     if (level < 1 || level > c->p.cbs_level) return c->fail(FHEAES_ERR_INVALID, "cbs level %u out of range", level);
@@ -893,6 +911,7 @@ int fheaes_cbs_pbs_batch(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, u
 
 int fheaes_pfpks_batch(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t m, uint64_t *ggsw_rows_out, int memspace)
 {
+    CtxLock lock__(c);
     TRY(check_keys(c));
     if (!lwe_in || !ggsw_rows_out) return c->fail(FHEAES_ERR_INVALID, "null pointer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -908,6 +927,7 @@ int fheaes_pfpks_batch(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t m, uint64
 
 int fheaes_forward_fourier_batch(fheaes_ctx *c, const uint64_t *polys_in, uint64_t polys, double *fourier_out, int memspace)
 {
+    CtxLock lock__(c);
     if (!c || !polys_in || !fourier_out) return c ? c->fail(FHEAES_ERR_INVALID, "null pointer") : FHEAES_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     if (memspace == FHEAES_DEVICE) return launch_forward_fourier(c, polys_in, polys, (double2 *)fourier_out, FHEAES_STAGE_GGSW_FFT);
@@ -922,6 +942,7 @@ int fheaes_forward_fourier_batch(fheaes_ctx *c, const uint64_t *polys_in, uint64
 int fheaes_vertical_packing_batch(fheaes_ctx *c, const double *ggsw_fourier, uint64_t n_inputs, uint32_t bits, const uint64_t *luts,
                                   uint32_t n_luts, int lut_per_input, uint64_t *lwe_out, int memspace)
 {
+    CtxLock lock__(c);
     if (!c || !ggsw_fourier || !luts || !lwe_out) return c ? c->fail(FHEAES_ERR_INVALID, "null pointer") : FHEAES_ERR_INVALID;
     if (bits < 1 || bits > 9 || n_luts < 1) return c->fail(FHEAES_ERR_INVALID, "bits must be 1..9 and n_luts >= 1");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -941,6 +962,7 @@ int fheaes_vertical_packing_batch(fheaes_ctx *c, const double *ggsw_fourier, uin
 int fheaes_wopbs_batch(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t n_inputs, uint32_t bits, const uint64_t *luts, uint32_t n_luts,
                        int lut_per_input, uint64_t *lwe_out, int memspace)
 {
+    CtxLock lock__(c);
     TRY(check_keys(c));
     if (!lwe_in || !luts || !lwe_out) return c->fail(FHEAES_ERR_INVALID, "null pointer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -963,6 +985,7 @@ static int many_sbox_dev(fheaes_ctx *c, const uint64_t *bytes, uint64_t n_bytes,
 
 int fheaes_many_sbox(fheaes_ctx *c, const uint64_t *bytes, uint64_t n_bytes, int inv, uint64_t *out, int memspace)
 {
+    CtxLock lock__(c);
     TRY(check_keys(c));
     if (!bytes || !out) return c->fail(FHEAES_ERR_INVALID, "null pointer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -979,6 +1002,7 @@ int fheaes_many_sbox(fheaes_ctx *c, const uint64_t *bytes, uint64_t n_bytes, int
 
 int fheaes_sbox(fheaes_ctx *c, uint64_t *bytes, uint64_t n_bytes, int inv, int memspace)
 {
+    CtxLock lock__(c);
     TRY(check_keys(c));
     if (!bytes) return c->fail(FHEAES_ERR_INVALID, "null pointer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1051,11 +1075,13 @@ static int aes_crypt(fheaes_ctx *c, const uint64_t *round_keys, uint64_t *state,
 
 int fheaes_aes_encrypt(fheaes_ctx *c, const uint64_t *round_keys, uint64_t *state, uint64_t n_blocks, int memspace)
 {
+    CtxLock lock__(c);
     return aes_crypt(c, round_keys, state, n_blocks, memspace, false);
 }
 
 int fheaes_aes_decrypt(fheaes_ctx *c, const uint64_t *round_keys, uint64_t *state, uint64_t n_blocks, int memspace)
 {
+    CtxLock lock__(c);
     return aes_crypt(c, round_keys, state, n_blocks, memspace, true);
 }
 
@@ -1086,6 +1112,7 @@ static int key_expansion_dev(fheaes_ctx *c, const uint64_t *key, uint64_t *w)
 
 int fheaes_aes_key_expansion(fheaes_ctx *c, const uint64_t *key, uint64_t *round_keys, int memspace)
 {
+    CtxLock lock__(c);
     TRY(check_keys(c));
     if (!key || !round_keys) return c->fail(FHEAES_ERR_INVALID, "null pointer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1144,6 +1171,7 @@ static int add_scalar_dev(fheaes_ctx *c, uint64_t *state, uint64_t n_blocks, con
 
 int fheaes_add_scalar(fheaes_ctx *c, uint64_t *state, uint64_t n_blocks, const uint64_t *counters_hi_lo, int memspace)
 {
+    CtxLock lock__(c);
     TRY(check_keys(c));
     if (!state || !counters_hi_lo) return c->fail(FHEAES_ERR_INVALID, "null pointer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1160,6 +1188,7 @@ int fheaes_add_scalar(fheaes_ctx *c, uint64_t *state, uint64_t n_blocks, const u
 // ---- measurement ------------------------------------------------------------------------------
 int fheaes_profile_enable(fheaes_ctx *c, int on)
 {
+    CtxLock lock__(c);
     if (!c) return FHEAES_ERR_INVALID;
     if (!on && c->prof) TRY(prof_flush(c));
     c->prof = on != 0;
@@ -1168,6 +1197,7 @@ int fheaes_profile_enable(fheaes_ctx *c, int on)
 
 int fheaes_profile_reset(fheaes_ctx *c)
 {
+    CtxLock lock__(c);
     if (!c) return FHEAES_ERR_INVALID;
     TRY(prof_flush(c));
     for (int s = 0; s < FHEAES_STAGE_COUNT; ++s) { c->stage_ms[s] = 0; c->stage_launches[s] = 0; c->stage_units[s] = 0; }
@@ -1176,6 +1206,7 @@ int fheaes_profile_reset(fheaes_ctx *c)
 
 int fheaes_profile_read(fheaes_ctx *c, int stage, double *total_ms, uint64_t *launches, uint64_t *units)
 {
+    CtxLock lock__(c);
     if (!c || stage < 0 || stage >= FHEAES_STAGE_COUNT) return FHEAES_ERR_INVALID;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     TRY(prof_flush(c));
