@@ -108,17 +108,20 @@ int fheaes_pfpks_batch(fheaes_ctx *ctx, const uint64_t *lwe_in, uint64_t m, uint
  *     out [polys][256][2] doubles (natural order, re/im interleaved). */
 int fheaes_forward_fourier_batch(fheaes_ctx *ctx, const uint64_t *polys_in, uint64_t polys, double *fourier_out, int memspace);
 /* K5  vertical_packing (many_wopbs.rs:277).  ggsw_fourier [n_inputs][bits][cbs_level][k+1][k+1][256][2];
- *     luts [n_sets][n_luts][bits][N] with n_sets = lut_per_input ? n_inputs : 1;
- *     out  [n_inputs][n_luts][bits][kN+1]. */
+ *     luts [n_sets][n_luts][bits][W] with n_sets = lut_per_input ? n_inputs : 1 and W = max(2^bits, N) words per
+ *     (LUT, output bit) as gen_lut.rs:19-23 sizes them; out [n_inputs][n_luts][bits][kN+1].
+ *     bits <= 9 (all the AES path uses): one LUT polynomial per output bit, blind rotation only.  9 < bits <= 16: the
+ *     2^(bits-9) polynomials go through the CMUX tree over input bits 9..bits-1 first, then the rotation over bits 0..8. */
 int fheaes_vertical_packing_batch(fheaes_ctx *ctx, const double *ggsw_fourier, uint64_t n_inputs, uint32_t bits,
                                   const uint64_t *luts, uint32_t n_luts, int lut_per_input, uint64_t *lwe_out, int memspace);
 
 /* ---- the plugin API of the path ------------------------------------------------ */
 /* many_wopbs_without_padding (many_wopbs.rs:31), batched over radix inputs.
- *   lwe_in [n_inputs][bits][kN+1], bits in {1..9}; luts as above; out [n_inputs][n_luts][bits][kN+1]. */
+ *   lwe_in [n_inputs][bits][kN+1], bits in {1..16}; luts as above; out [n_inputs][n_luts][bits][kN+1]. */
 int fheaes_wopbs_batch(fheaes_ctx *ctx, const uint64_t *lwe_in, uint64_t n_inputs, uint32_t bits,
                        const uint64_t *luts, uint32_t n_luts, int lut_per_input, uint64_t *lwe_out, int memspace);
-/* gen_lut (gen_lut.rs:9) for message_modulus 2, carry_modulus 1: f_table[2^nb_block] -> out [nb_block][N] (host only). */
+/* gen_lut (gen_lut.rs:9) for message_modulus 2, carry_modulus 1: f_table[2^nb_block] -> out [nb_block][max(2^nb_block, N)]
+ * (host only), nb_block in 1..16. */
 int fheaes_gen_lut(uint32_t nb_block, const uint64_t *f_table, uint64_t *lut_out);
 /* sbox (sbox.rs:46), in place over n_bytes bytes: bytes [n_bytes][8][kN+1]; inv = 0 SBOX, 1 INV_SBOX. */
 int fheaes_sbox(fheaes_ctx *ctx, uint64_t *bytes, uint64_t n_bytes, int inv, int memspace);

@@ -575,15 +575,33 @@ void orc_circuit_bootstrap(const orc_keys *K, const uint64_t *lwe_small, uint64_
 /* K5: vertical packing (many_wopbs.rs:267-279)                  */
 /* ------------------------------------------------------------------------- */
 /* ggswf: nbits planar-Fourier GGSWs, index j = input bit j (weight 2^j). lut: one poly. */
+/* vertical_packing (many_wopbs.rs:277).  `lut` holds max(2^nbits, 512) entries of ONE output bit, i.e.
+ * P = max(1, 2^(nbits-9)) polynomials (gen_lut.rs:19-39: entry idx belongs to polynomial idx / 512).  For nbits > 9 a CMUX tree
+ * over input bits 9..nbits-1 (bit 9 at the leaves, the most significant bit at the root) selects the polynomial
+ * value >> 9: cmux(g, ct0, ct1) = ct0 + g (x) (ct1 - ct0); the blind rotation over bits 0..8 then selects the coefficient.
+ * For nbits <= 9 the tree is degenerate (one polynomial), which is all the AES path uses. */
 static void vertical_packing(const orc_params *p, const double *ggswf, int nbits, const uint64_t *lut, uint64_t *lwe_out)
 {
     int k1 = K1(p);
     size_t gsz = (size_t)k1 * NPOLY;
     size_t gstride = (size_t)p->cbs_level * k1 * k1 * NPOLY;
-    uint64_t *ct0 = (uint64_t *)calloc(gsz, sizeof(uint64_t));
+    int tree_bits = nbits > 9 ? nbits - 9 : 0;
+    size_t polys = (size_t)1 << tree_bits;
+    uint64_t *tree = (uint64_t *)calloc(polys * gsz, sizeof(uint64_t));
     uint64_t *ct1 = (uint64_t *)malloc(gsz * sizeof(uint64_t));
-    memcpy(ct0 + (size_t)p->k * NPOLY, lut, NPOLY * sizeof(uint64_t));
-    for (int j = 0; j < nbits; ++j) {
+    for (size_t j = 0; j < polys; ++j) memcpy(tree + j * gsz + (size_t)p->k * NPOLY, lut + j * NPOLY, NPOLY * sizeof(uint64_t));
+    for (int tb = 0; tb < tree_bits; ++tb) {
+        size_t nodes = polys >> (tb + 1);
+        for (size_t m = 0; m < nodes; ++m) {
+            uint64_t *a = tree + (2 * m) * gsz, *b = tree + (2 * m + 1) * gsz;
+            for (size_t c = 0; c < gsz; ++c) ct1[c] = b[c] - a[c];
+            ext_product_add(k1, p->cbs_level, p->cbs_base_log, ggswf + (size_t)(9 + tb) * gstride, ct1, a);
+            if (m) memcpy(tree + m * gsz, a, gsz * sizeof(uint64_t));
+        }
+    }
+    uint64_t *ct0 = tree;
+    int rot_bits = nbits < 9 ? nbits : 9;
+    for (int j = 0; j < rot_bits; ++j) {
         int deg = 1 << j;
         for (int r = 0; r < k1; ++r) {
             poly_mul_monomial(ct0 + (size_t)r * NPOLY, (1024 - deg) & 1023, ct1 + (size_t)r * NPOLY);
@@ -592,14 +610,14 @@ static void vertical_packing(const orc_params *p, const double *ggswf, int nbits
         ext_product_add(k1, p->cbs_level, p->cbs_base_log, ggswf + (size_t)j * gstride, ct1, ct0);
     }
     sample_extract(p->k, ct0, lwe_out);
-    free(ct0); free(ct1);
+    free(tree); free(ct1);
 }
 
 /* ------------------------------------------------------------------------- */
 /* many_wopbs_without_padding (many_wopbs.rs:31-116), batched                  */
 /* ------------------------------------------------------------------------- */
 /* lwe_in : [n_inputs][nbits][kN+1]   bit j of input i (block j, LSB first)
- * luts   : [n_lut_sets][n_luts][nbits][512]; input i uses set (lut_per_input ? i : 0)
+ * luts   : [n_lut_sets][n_luts][nbits][W], W = max(2^nbits, 512) (gen_lut.rs:19-23); input i uses set (lut_per_input ? i : 0)
  * lwe_out: [n_inputs][n_luts][nbits][kN+1]
  * dbg_small / dbg_pbs / dbg_ggsw: optional dumps of intermediates (may be NULL):
  *   dbg_small [n_inputs][nbits][n+1], dbg_pbs [n_inputs][nbits][kN+1] (cbs level 1 only),
@@ -634,7 +652,8 @@ void orc_wopbs_batch(const orc_keys *K, const uint64_t *lwe_in, int n_inputs, in
             int64_t i = q / ((int64_t)n_luts * nbits);
             int64_t rem = q % ((int64_t)n_luts * nbits);
             int64_t set = lut_per_input ? i : 0;
-            const uint64_t *lut = luts + ((size_t)set * n_luts * nbits + (size_t)rem) * NPOLY;
+            const size_t lut_words = nbits > 9 ? ((size_t)1 << nbits) : NPOLY;
+            const uint64_t *lut = luts + ((size_t)set * n_luts * nbits + (size_t)rem) * lut_words;
             vertical_packing(p, ggswf + (size_t)i * nbits * gstd, nbits, lut, lwe_out + (size_t)q * big1);
         }
     }
@@ -670,12 +689,13 @@ static void init_tables(void)
 
 void orc_get_tables(uint8_t *sbox, uint8_t *inv_sbox) { init_tables(); memcpy(sbox, SBOX_T, 256); memcpy(inv_sbox, INV_SBOX_T, 256); }
 
-/* lut[b][idx] = ((f(idx & (2^nb-1)) >> b) & 1) << 63, idx < max(2^nb, 512); nb <= 9 so size is 512 */
-void orc_gen_lut(int nb_block, const uint64_t *f_table /*[2^nb]*/, uint64_t *out /*[nb][512]*/)
+/* gen_lut.rs:9-42: lut[b][idx] = ((f(idx & (2^nb-1)) >> b) & 1) << 63, idx < W = max(2^nb, 512) */
+void orc_gen_lut(int nb_block, const uint64_t *f_table /*[2^nb]*/, uint64_t *out /*[nb][W]*/)
 {
-    for (int idx = 0; idx < NPOLY; ++idx) {
-        uint64_t v = f_table[idx & ((1 << nb_block) - 1)];
-        for (int b = 0; b < nb_block; ++b) out[(size_t)b * NPOLY + idx] = ((v >> b) & 1ULL) << 63;
+    size_t W = nb_block > 9 ? ((size_t)1 << nb_block) : NPOLY;
+    for (size_t idx = 0; idx < W; ++idx) {
+        uint64_t v = f_table[idx & (((size_t)1 << nb_block) - 1)];
+        for (int b = 0; b < nb_block; ++b) out[(size_t)b * W + idx] = ((v >> b) & 1ULL) << 63;
     }
 }
 

@@ -155,7 +155,7 @@ def tables():
 def gen_lut(nb_block: int, f_table) -> np.ndarray:
     f = np.ascontiguousarray(f_table, dtype=np.uint64)
     assert f.size == 1 << nb_block
-    out = np.empty((nb_block, 512), dtype=np.uint64)
+    out = np.empty((nb_block, max(512, 1 << nb_block)), dtype=np.uint64)
     lib().orc_gen_lut(nb_block, _u64(f), _u64(out))
     return out
 
@@ -221,7 +221,7 @@ class Oracle:
         return out
 
     def wopbs_batch(self, lwe_in: np.ndarray, luts: np.ndarray, lut_per_input: bool = False, debug: bool = False):
-        """lwe_in [n_inputs][bits][kN+1]; luts [n_sets][n_luts][bits][512] or [n_luts][bits][512]."""
+        """lwe_in [n_inputs][bits][kN+1]; luts [n_sets][n_luts][bits][W] or [n_luts][bits][W], W = max(2^bits, 512)."""
         p = self.params
         x = np.ascontiguousarray(lwe_in, dtype=np.uint64)
         n_inputs, bits = x.shape[0], x.shape[1]
@@ -229,7 +229,7 @@ class Oracle:
         if luts.ndim == 3:
             luts = luts[None]
         n_luts = luts.shape[1]
-        assert luts.shape[2] == bits and luts.shape[0] == (n_inputs if lut_per_input else 1)
+        assert luts.shape[2] == bits and luts.shape[0] == (n_inputs if lut_per_input else 1) and luts.shape[3] == max(512, 1 << bits)
         out = np.empty((n_inputs, n_luts, bits, p.big1), dtype=np.uint64)
         dbg = [None, None, None]
         ptrs = [None, None, None]

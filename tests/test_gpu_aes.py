@@ -45,6 +45,27 @@ def test_many_wopbs_9bit_with_per_input_luts(toy, toy_server):
         assert int(sum(int(dec[i, 0, j]) << j for j in range(8))) == s % 256 and int(dec[i, 1, 0]) == (1 if s > 255 else 0)
 
 
+@pytest.mark.parametrize("nb,n_luts", [(10, 2), (12, 1)])
+def test_many_wopbs_wider_than_log_n_uses_the_cmux_tree(toy, toy_server, nb, n_luts):
+    """inputs wider than log2 N = 9 bits: gen_lut makes 2^(nb-9) polynomials per output bit (gen_lut.rs:19-39) and
+    vertical_packing (many_wopbs.rs:277) selects one through a CMUX tree over the high bits before the blind rotation
+    (SURVEY.md A.8).  Not used by AES; completes many_wopbs_without_padding.  Bit-exact against the oracle + decrypts to f(x)."""
+    c = toy.client
+    fs = [lambda v: (v * 37 + 5) % (1 << nb), lambda v: (v ^ (v >> 3) ^ 0x155) % (1 << nb)][:n_luts]
+    luts = [gen_lut(2, 1, 512, nb, f) for f in fs]
+    assert luts[0].shape == (nb, 1 << nb)
+    vals = [0, 1, (1 << nb) - 1, 0x2A5 % (1 << nb), 513, 1 << (nb - 1)]
+    bits = np.array([[(v >> j) & 1 for j in range(nb)] for v in vals], dtype=np.uint8)
+    x = c.encrypt_bits(bits)
+    got = toy_server.many_wopbs_without_padding(x, luts)
+    want = toy.oracle.wopbs_batch(x, np.stack(luts))
+    assert np.array_equal(got, want)
+    dec = c.decrypt_bits(got)
+    for i, v in enumerate(vals):
+        for li, f in enumerate(fs):
+            assert int(sum(int(dec[i, li, j]) << j for j in range(nb))) == f(v), (v, li)
+
+
 def test_sbox_and_many_sbox(toy, toy_server):
     c = toy.client
     vals = [0x3C, 0x00, 0x80]

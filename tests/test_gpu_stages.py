@@ -137,7 +137,7 @@ def test_errors_are_status_codes(toy):
         E.upload_keys(toy.keys.ksk[:-1].copy(), toy.keys.bsk, toy.keys.pfpksk)
     E2 = toy.engine()
     luts = orc.build_lutset(orc.LUTSET_SBOX)
-    for bits in (0, 10):
+    for bits in (0, 17):                                                 # 1..16 are valid (9 < bits: CMUX tree first)
         with pytest.raises(_native.FheAesError) as e:
             E2.wopbs_batch(np.zeros((1, max(bits, 1), p.big1), dtype=np.uint64), 1, bits, luts, 1, False,
                            np.zeros((1, 1, max(bits, 1), p.big1), dtype=np.uint64))

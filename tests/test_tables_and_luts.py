@@ -54,7 +54,8 @@ def _gen_lut_restated(nb_block, f):
 
 def test_gen_lut_matches_reference_semantics():
     for nb, f in ((8, lambda x: aes_clear.SBOX[x]), (8, lambda x: (x + 77) % 256), (9, lambda x: ((x & 0xFF) + (x >> 8) + 200) % 256),
-                  (9, lambda x: 1 if (x & 0xFF) + (x >> 8) + 200 > 255 else 0), (1, lambda x: x ^ 1)):
+                  (9, lambda x: 1 if (x & 0xFF) + (x >> 8) + 200 > 255 else 0), (1, lambda x: x ^ 1),
+                  (10, lambda x: (x * 37 + 5) % 1024), (12, lambda x: (x ^ (x >> 3)) % 4096)):      # lut_size = 2^nb > 512 (gen_lut.rs:19-23)
         want = _gen_lut_restated(nb, f)
         table = [f(x) for x in range(1 << nb)]
         assert np.array_equal(orc.gen_lut(nb, table), want)

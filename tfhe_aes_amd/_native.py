@@ -252,7 +252,7 @@ def gen_lut(nb_block: int, f_table) -> np.ndarray:
     f = np.ascontiguousarray(f_table, dtype=np.uint64)
     if f.size != 1 << nb_block:
         raise ValueError("f_table must have 2^nb_block entries")
-    out = np.empty((nb_block, 512), dtype=np.uint64)
+    out = np.empty((nb_block, max(512, 1 << nb_block)), dtype=np.uint64)
     rc = load_library().fheaes_gen_lut(nb_block, f.ctypes.data_as(_u64p), out.ctypes.data_as(_u64p))
     if rc != 0:
         raise FheAesError(rc, "fheaes_gen_lut")

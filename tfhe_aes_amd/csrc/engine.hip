@@ -30,6 +30,7 @@
 
 #define FHEAES_VERSION_STR "fheaes-mi355x 0.1 (gfx950)"
 #define MAX_CHUNK_BITS 32768ull
+#define MAX_WOPBS_BITS 16u            /* widest radix input of many_wopbs_without_padding (LUT of 2^16 entries per output bit) */
 #ifndef SMALL_BATCH_BITS
 #define SMALL_BATCH_BITS 512ull    /* at most 2 one-ciphertext workgroups per CU */
 #endif
@@ -112,11 +113,15 @@ const AesTables &aes_tables()
 
 enum { LUTSET_ENC_ROUND = 0, LUTSET_SBOX, LUTSET_INV_SBOX, LUTSET_DEC_MUL, LUTSET_IDENTITY, LUTSET_COUNT };
 
+// words of one (LUT, output bit) row: gen_lut.rs:19-23, lut_size = max(2^nb_block, polynomial_size)
+inline uint64_t lut_row_words(uint32_t nb) { return nb > 9 ? (1ull << nb) : (uint64_t)FHE_N; }
+
 void gen_lut_host(uint32_t nb, const uint64_t *f, uint64_t *out)
 {
-    for (uint32_t idx = 0; idx < FHE_N; ++idx) {
-        uint64_t v = f[idx & ((1u << nb) - 1)];
-        for (uint32_t b = 0; b < nb; ++b) out[(size_t)b * FHE_N + idx] = ((v >> b) & 1ull) << 63;
+    const uint64_t W = lut_row_words(nb);
+    for (uint64_t idx = 0; idx < W; ++idx) {
+        uint64_t v = f[idx & ((1ull << nb) - 1)];
+        for (uint32_t b = 0; b < nb; ++b) out[(size_t)b * W + idx] = ((v >> b) & 1ull) << 63;
     }
 }
 
@@ -205,7 +210,7 @@ struct fheaes_ctx {
     uint64_t *lutset_d[LUTSET_COUNT] = {};
     int lutset_n[LUTSET_COUNT] = {};
     // workspace
-    DevBuf ws_small, ws_pbs, ws_ggsw, ws_ggswf, ws_vp, ws_tmp_a, ws_tmp_b, ws_luts, ws_misc, ws_digits, ws_park;
+    DevBuf ws_small, ws_pbs, ws_ggsw, ws_ggswf, ws_vp, ws_tmp_a, ws_tmp_b, ws_luts, ws_misc, ws_digits, ws_park, ws_tree;
     DevBuf stage[4];                     // host-memspace calls stage their arguments here (grow-only, reused)
     // pinned host staging for the counter bytes of add_scalar; `pin_ev` marks the last copy out of it
     uint8_t *pin = nullptr;
@@ -498,10 +503,42 @@ int launch_vertical_packing(fheaes_ctx *c, const double2 *ggswf, uint64_t n_inpu
 {
     if (n_inputs == 0) return FHEAES_OK;
     StageScope sc(c, FHEAES_STAGE_VERTICAL_PACKING, n_inputs * n_luts * bits);
+    const uint32_t inst_per_input = n_luts * bits;
+    const uint64_t W = lut_row_words(bits);
+    // ---- inputs wider than 9 bits: CMUX tree over bits 9..bits-1 (kern_extprod.h, cmux_level_kernel), root -> ws_tree ----
+    const uint64_t *glwe_root = nullptr;
+    if (bits > 9) {
+        const uint32_t tree_bits = bits - 9;
+        const uint64_t instances = n_inputs * inst_per_input, gsz = (uint64_t)c->k1 * FHE_N;
+        // level t writes (2^(tree_bits-1-t)) nodes per instance; ping-pong between the two halves of ws_tree
+        const uint64_t half_words = instances * (1ull << (tree_bits - 1)) * gsz;
+        TRY(ensure(c, c->ws_tree, 2 * half_words * 8));
+        uint64_t *buf[2] = {(uint64_t *)c->ws_tree.p, (uint64_t *)c->ws_tree.p + half_words};
+        for (uint32_t t = 0; t < tree_bits; ++t) {
+            CmuxArgs a{};
+            a.ggsw = ggswf; a.psi = c->psi_d; a.tw = c->tw_d; a.fc = c->fc;
+            a.luts = t == 0 ? luts : nullptr; a.in = t == 0 ? nullptr : buf[(t - 1) & 1]; a.out = buf[t & 1];
+            a.bits = bits; a.bit = 9 + t; a.nodes_out = 1u << (tree_bits - 1 - t);
+            a.inst_per_input = inst_per_input; a.lut_per_input = per_input ? 1 : 0; a.lut_words = W;
+            const uint64_t jobs = (uint64_t)inst_per_input * a.nodes_out;
+            if (c->k1 == 5) {
+                constexpr int R = 3;
+                a.wg_per_input = (uint32_t)((jobs + R - 1) / R);
+                hipLaunchKernelGGL((cmux_level_kernel<5, 15, R>), dim3((unsigned)(n_inputs * a.wg_per_input)), dim3(EP_THREADS), 0, c->stream, a);
+            } else {
+                constexpr int R = 8;
+                a.wg_per_input = (uint32_t)((jobs + R - 1) / R);
+                hipLaunchKernelGGL((cmux_level_kernel<2, 15, R>), dim3((unsigned)(n_inputs * a.wg_per_input)), dim3(EP_THREADS), 0, c->stream, a);
+            }
+            HIP_TRY(c, hipGetLastError());
+        }
+        glwe_root = buf[(tree_bits - 1) & 1];
+    }
     ExtProdArgs a{};
     a.ggsw = ggswf; a.psi = c->psi_d; a.tw = c->tw_d; a.fc = c->fc;
-    a.out = out; a.count = n_inputs * n_luts * bits; a.iters = bits;
-    a.luts = luts; a.n_luts = n_luts; a.lut_per_input = per_input ? 1 : 0; a.inst_per_input = n_luts * bits;
+    a.out = out; a.count = n_inputs * n_luts * bits; a.iters = bits < 9 ? bits : 9; a.ggsw_per_input = bits;
+    a.luts = luts; a.lut_words = W; a.glwe_in = glwe_root;
+    a.n_luts = n_luts; a.lut_per_input = per_input ? 1 : 0; a.inst_per_input = inst_per_input;
     if (c->k1 == 5) {
         constexpr int R = 3;
         a.wg_per_input = (a.inst_per_input + R - 1) / R;
@@ -557,10 +594,16 @@ int check_keys(fheaes_ctx *c)
 int wopbs_dev(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t n_inputs, uint32_t bits, const uint64_t *luts, uint32_t n_luts,
               int per_input, uint64_t *lwe_out)
 {
-    if (bits < 1 || bits > 9) return c->fail(FHEAES_ERR_INVALID, "bits_per_input must be in 1..9 (got %u)", bits);
+    if (bits < 1 || bits > MAX_WOPBS_BITS) return c->fail(FHEAES_ERR_INVALID, "bits_per_input must be in 1..%u (got %u)", MAX_WOPBS_BITS, bits);
     if (n_luts < 1) return c->fail(FHEAES_ERR_INVALID, "n_luts must be >= 1");
     if (n_inputs == 0) return FHEAES_OK;
-    const uint64_t chunk_inputs = std::max<uint64_t>(1, MAX_CHUNK_BITS / bits);
+    uint64_t chunk_inputs = std::max<uint64_t>(1, MAX_CHUNK_BITS / bits);
+    if (bits > 9) {
+        // the CMUX tree keeps 2^(bits-9) GLWEs per (input, LUT, output bit) in flight: bound that workspace to ~2 GiB per chunk
+        const uint64_t per_input = (uint64_t)n_luts * bits * (1ull << (bits - 9)) * c->k1 * FHE_N * 8;
+        chunk_inputs = std::max<uint64_t>(1, std::min<uint64_t>(chunk_inputs, (2ull << 30) / per_input));
+    }
+    const uint64_t W = lut_row_words(bits);
     const uint64_t ggsw_words = (uint64_t)c->k1 * c->k1 * FHE_N;    // cbs_level == 1
     const uint64_t cap_bits = std::min<uint64_t>(n_inputs, chunk_inputs) * bits;
     TRY(ensure(c, c->ws_small, cap_bits * (c->n + 1) * 8));
@@ -575,7 +618,7 @@ int wopbs_dev(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t n_inputs, uint32_t
         TRY(launch_cbs_pbs(c, (const uint64_t *)c->ws_small.p, m, 1, (uint64_t *)c->ws_pbs.p));
         TRY(launch_pfpks(c, (const uint64_t *)c->ws_pbs.p, m, (uint64_t *)c->ws_ggsw.p, ggsw_words));
         TRY(launch_forward_fourier(c, (const uint64_t *)c->ws_ggsw.p, m * c->k1 * c->k1, (double2 *)c->ws_ggswf.p, FHEAES_STAGE_GGSW_FFT));
-        const uint64_t *l = per_input ? luts + i0 * n_luts * bits * FHE_N : luts;
+        const uint64_t *l = per_input ? luts + i0 * n_luts * bits * W : luts;
         TRY(launch_vertical_packing(c, (const double2 *)c->ws_ggswf.p, ni, bits, l, n_luts, per_input, lwe_out + i0 * n_luts * bits * c->big1));
     }
     return FHEAES_OK;
@@ -645,7 +688,7 @@ int fheaes_get_twiddles(double *psi_out)
 
 int fheaes_gen_lut(uint32_t nb_block, const uint64_t *f_table, uint64_t *lut_out)
 {
-    if (nb_block < 1 || nb_block > 9 || !f_table || !lut_out) return FHEAES_ERR_INVALID;
+    if (nb_block < 1 || nb_block > MAX_WOPBS_BITS || !f_table || !lut_out) return FHEAES_ERR_INVALID;
     gen_lut_host(nb_block, f_table, lut_out);
     return FHEAES_OK;
 }
@@ -700,7 +743,7 @@ void fheaes_destroy(fheaes_ctx *c)
     for (auto ev : c->free_events) (void)hipEventDestroy(ev);
     void *ptrs[] = {c->ksk_frag, c->pfpksk_frag, c->bskf, c->psi_d, c->tw_d, c->ws_digits.p,
                     c->ws_small.p, c->ws_pbs.p, c->ws_ggsw.p, c->ws_ggswf.p, c->ws_vp.p, c->ws_tmp_a.p, c->ws_tmp_b.p, c->ws_luts.p, c->ws_misc.p,
-                    c->ws_park.p};
+                    c->ws_park.p, c->ws_tree.p};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &b : c->stage) if (b.p) (void)hipFree(b.p);
     if (c->pin) (void)hipHostFree(c->pin);
@@ -944,7 +987,7 @@ int fheaes_vertical_packing_batch(fheaes_ctx *c, const double *ggsw_fourier, uin
 {
     CtxLock lock__(c);
     if (!c || !ggsw_fourier || !luts || !lwe_out) return c ? c->fail(FHEAES_ERR_INVALID, "null pointer") : FHEAES_ERR_INVALID;
-    if (bits < 1 || bits > 9 || n_luts < 1) return c->fail(FHEAES_ERR_INVALID, "bits must be 1..9 and n_luts >= 1");
+    if (bits < 1 || bits > MAX_WOPBS_BITS || n_luts < 1) return c->fail(FHEAES_ERR_INVALID, "bits must be 1..%u and n_luts >= 1", MAX_WOPBS_BITS);
     HIP_TRY(c, hipSetDevice(c->device));
     if (memspace == FHEAES_DEVICE) return launch_vertical_packing(c, (const double2 *)ggsw_fourier, n_inputs, bits, luts, n_luts, lut_per_input, lwe_out);
     Staged s(c);
@@ -952,7 +995,7 @@ int fheaes_vertical_packing_batch(fheaes_ctx *c, const double *ggsw_fourier, uin
     const uint64_t gw = (uint64_t)c->k1 * c->k1 * FHE_N;
     const uint64_t sets = lut_per_input ? n_inputs : 1;
     TRY(s.in(ggsw_fourier, n_inputs * bits * gw * 8, &dg));
-    TRY(s.in(luts, sets * n_luts * bits * FHE_N * 8, &dl));
+    TRY(s.in(luts, sets * n_luts * bits * lut_row_words(bits) * 8, &dl));
     TRY(s.alloc(&dout, n_inputs * n_luts * bits * c->big1 * 8));
     TRY(launch_vertical_packing(c, (const double2 *)dg, n_inputs, bits, (const uint64_t *)dl, n_luts, lut_per_input, (uint64_t *)dout));
     return s.out(lwe_out, dout, n_inputs * n_luts * bits * c->big1 * 8);
@@ -967,12 +1010,12 @@ int fheaes_wopbs_batch(fheaes_ctx *c, const uint64_t *lwe_in, uint64_t n_inputs,
     if (!lwe_in || !luts || !lwe_out) return c->fail(FHEAES_ERR_INVALID, "null pointer");
     HIP_TRY(c, hipSetDevice(c->device));
     if (memspace == FHEAES_DEVICE) return wopbs_dev(c, lwe_in, n_inputs, bits, luts, n_luts, lut_per_input, lwe_out);
-    if (bits < 1 || bits > 9 || n_luts < 1) return c->fail(FHEAES_ERR_INVALID, "bits must be 1..9 and n_luts >= 1");
+    if (bits < 1 || bits > MAX_WOPBS_BITS || n_luts < 1) return c->fail(FHEAES_ERR_INVALID, "bits must be 1..%u and n_luts >= 1", MAX_WOPBS_BITS);
     Staged s(c);
     void *din, *dl, *dout;
     const uint64_t sets = lut_per_input ? n_inputs : 1;
     TRY(s.in(lwe_in, n_inputs * bits * c->big1 * 8, &din));
-    TRY(s.in(luts, sets * n_luts * bits * FHE_N * 8, &dl));
+    TRY(s.in(luts, sets * n_luts * bits * lut_row_words(bits) * 8, &dl));
     TRY(s.alloc(&dout, n_inputs * n_luts * bits * c->big1 * 8));
     TRY(wopbs_dev(c, (const uint64_t *)din, n_inputs, bits, (const uint64_t *)dl, n_luts, lut_per_input, (uint64_t *)dout));
     return s.out(lwe_out, dout, n_inputs * n_luts * bits * c->big1 * 8);

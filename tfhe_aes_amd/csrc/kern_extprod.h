@@ -55,6 +55,9 @@ struct ExtProdArgs {
     uint32_t lut_per_input;
     uint32_t inst_per_input;    // n_luts * bits
     uint32_t wg_per_input;      // ceil(inst_per_input / R)
+    uint32_t ggsw_per_input;    // VP: GGSWs per input in `ggsw` (= input bits; `iters` of them, the low bits, drive the rotation)
+    uint64_t lut_words;         // VP: words per (LUT, output bit) in `luts` (512, or 2^bits when a CMUX tree ran first)
+    const uint64_t *glwe_in;    // VP: non-null: the accumulator starts from this GLWE [instance][K1][512] (root of the CMUX tree)
     uint64_t *park;             // kern_blindrot32.h: accumulator parking space, 64 KB per workgroup
 #ifdef EP_STAMPS
     unsigned long long *stamps; // developer build: per-wave cycles per phase [grid][4 waves][EP_NPH]
@@ -135,13 +138,19 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
             hi[a] = (p_own == K1 - 1) ? v1 : 0;
         }
     } else {
-        uint64_t local = inst % A.inst_per_input;
-        uint64_t set = A.lut_per_input ? input : 0;
-        const uint64_t *lut = A.luts + (set * A.inst_per_input + local) * FHE_N;
+        if (A.glwe_in) {
+            const uint64_t *src = A.glwe_in + (inst * K1 + p_own) * FHE_N;
 #pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            lo[a] = (p_own == K1 - 1) ? lut[16 * a + b] : 0;
-            hi[a] = (p_own == K1 - 1) ? lut[256 + 16 * a + b] : 0;
+            for (int a = 0; a < 16; ++a) { lo[a] = src[16 * a + b]; hi[a] = src[256 + 16 * a + b]; }
+        } else {
+            uint64_t local = inst % A.inst_per_input;
+            uint64_t set = A.lut_per_input ? input : 0;
+            const uint64_t *lut = A.luts + (set * A.inst_per_input + local) * A.lut_words;
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                lo[a] = (p_own == K1 - 1) ? lut[16 * a + b] : 0;
+                hi[a] = (p_own == K1 - 1) ? lut[256 + 16 * a + b] : 0;
+            }
         }
     }
     __syncthreads();   // tables visible
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
             G = A.ggsw + (size_t)it * ggsw_stride;
         } else {
             t = (1024 - (1 << it)) & 1023;
-            G = A.ggsw + ((size_t)input * A.iters + it) * ggsw_stride;
+            G = A.ggsw + ((size_t)input * A.ggsw_per_input + it) * ggsw_stride;
         }
 
         // ---- d = acc * X^t - acc, first decomposition level -----------------------------------
@@ -369,6 +378,136 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
             }
         } else if (b == 0) {
             o[big] = lo[0] + (VP ? 0 : A.post_add);
+        }
+    }
+}
+
+// ---- CMUX tree of vertical_packing for inputs wider than log2(N) = 9 bits (upstream vertical_packing, called
+//      at many_wopbs.rs:277) ----------------------------------------------------------------------------------------------
+// A LUT of 2^bits entries per output bit is P = 2^(bits-9) polynomials; input bits 9..bits-1 select one of them through a
+// binary tree of CMUXes (bit 9 at the leaves), then the blind rotation over bits 0..8 selects the coefficient.  One launch per
+// tree level: job = (instance, node) computes  out = ct0 + GGSW_bit (x) (ct1 - ct0)  with ct0 / ct1 = children 2*node, 2*node+1
+// (leaf level: trivial GLWEs of LUT polynomials).  Same lane mapping and arithmetic as one iteration of the kernel above with
+// one decomposition level.  Not on the AES path (8- and 9-bit inputs only); it completes many_wopbs_without_padding.
+struct CmuxArgs {
+    const double2 *ggsw;        // Fourier GGSWs [n_inputs][bits][K1][K1][256]
+    const double2 *psi, *tw;
+    FftConsts fc;
+    const uint64_t *luts;       // leaf level: [n_sets][inst_per_input][lut_words]; else null
+    const uint64_t *in;         // inner levels: GLWE [instances][2 * nodes_out][K1][512]
+    uint64_t *out;              // GLWE [instances][nodes_out][K1][512]
+    uint32_t bits, bit;         // GGSWs per input; which of them drives this level
+    uint32_t nodes_out;         // nodes per instance after this level
+    uint32_t inst_per_input;    // n_luts * bits
+    uint32_t lut_per_input;
+    uint32_t wg_per_input;      // ceil(inst_per_input * nodes_out / R)
+    uint64_t lut_words;
+};
+
+template <int K1, int BASE_LOG, int R>
+__global__ __launch_bounds__(EP_THREADS, 2) void cmux_level_kernel(const CmuxArgs A)
+{
+    static_assert(R * K1 <= EP_GROUPS, "too many polynomials for 16 lane groups");
+    __shared__ __attribute__((aligned(16))) double lds[EP_LDS_DOUBLES];
+    double2 *psi = reinterpret_cast<double2 *>(lds + EP_GROUPS * GROUP_TILE_DOUBLES);
+    double2 *tw = psi + FHE_H;
+    const int tid = threadIdx.x;
+    const int g = tid >> 4, b = tid & 15;
+    const bool owner = g < R * K1;
+    const int r_own = owner ? g / K1 : R - 1;
+    const int p_own = owner ? g % K1 : K1 - 1;
+    double *tile = lds + g * GROUP_TILE_DOUBLES;
+    const FftConsts fc = A.fc;
+    psi[tid] = A.psi[tid];
+    tw[tid] = A.tw[tid];
+
+    const uint64_t input = blockIdx.x / A.wg_per_input;
+    const uint32_t jobs_per_input = A.inst_per_input * A.nodes_out;
+    uint32_t local = (blockIdx.x % A.wg_per_input) * R + r_own;
+    const bool valid = owner && local < jobs_per_input;
+    if (local >= jobs_per_input) local = jobs_per_input - 1;
+    const uint32_t instl = local / A.nodes_out, node = local % A.nodes_out;
+    const uint64_t inst = input * A.inst_per_input + instl;
+
+    uint64_t c0lo[16], c0hi[16];
+    double xr[16], xi[16];
+    {
+        const uint64_t *p0, *p1;
+        bool zero = false;
+        if (A.luts) {
+            const uint64_t set = A.lut_per_input ? input : 0;
+            const uint64_t *lut = A.luts + (set * A.inst_per_input + instl) * A.lut_words;
+            p0 = lut + (uint64_t)(2 * node) * FHE_N;
+            p1 = p0 + FHE_N;
+            zero = p_own != K1 - 1;                          // trivial GLWE: only the body polynomial is non-zero
+        } else {
+            p0 = A.in + ((inst * (2 * A.nodes_out) + 2 * node) * K1 + p_own) * FHE_N;
+            p1 = p0 + (uint64_t)K1 * FHE_N;
+        }
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            const uint64_t a0 = zero ? 0 : p0[16 * a + b], a1 = zero ? 0 : p0[256 + 16 * a + b];
+            const uint64_t b0 = zero ? 0 : p1[16 * a + b], b1 = zero ? 0 : p1[256 + 16 * a + b];
+            c0lo[a] = a0; c0hi[a] = a1;
+            uint32_t st;
+            xr[a] = (double)decompose_first<BASE_LOG, 1>(b0 - a0, st);
+            xi[a] = (double)decompose_first<BASE_LOG, 1>(b1 - a1, st);
+        }
+    }
+    __syncthreads();   // tables visible
+    nega_fwd(xr, xi, psi, tw, tile, b, fc);
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+        double2 v; v.x = xr[k2]; v.y = xi[k2];
+        *reinterpret_cast<double2 *>(tile + 2 * (b + 16 * k2)) = v;
+    }
+    __syncthreads();
+    // multiply-accumulate role: thread tid owns Fourier point tid
+    double fr[R][K1], fi[R][K1];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < K1; ++c) { fr[r][c] = 0.0; fi[r][c] = 0.0; }
+    const double2 *G = A.ggsw + ((size_t)input * A.bits + A.bit) * (size_t)(K1 * K1 * FHE_H) + tid;
+#pragma unroll
+    for (int p = 0; p < K1; ++p) {
+        double2 bv[K1];
+#pragma unroll
+        for (int c = 0; c < K1; ++c) bv[c] = G[(size_t)(p * K1 + c) * FHE_H];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double2 d = *reinterpret_cast<const double2 *>(lds + (r * K1 + p) * GROUP_TILE_DOUBLES + 2 * tid);
+#pragma unroll
+            for (int c = 0; c < K1; ++c) {
+                fr[r][c] = __builtin_fma(d.x, bv[c].x, fr[r][c]);
+                fr[r][c] = __builtin_fma(-d.y, bv[c].y, fr[r][c]);
+                fi[r][c] = __builtin_fma(d.x, bv[c].y, fi[r][c]);
+                fi[r][c] = __builtin_fma(d.y, bv[c].x, fi[r][c]);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < K1; ++c) {
+            double2 v; v.x = fr[r][c]; v.y = fi[r][c];
+            *reinterpret_cast<double2 *>(lds + (r * K1 + c) * GROUP_TILE_DOUBLES + 2 * tid) = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+        double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (b + 16 * k2));
+        xr[k2] = v.x; xi[k2] = v.y;
+    }
+    wave_lds_sync();
+    nega_inv(xr, xi, psi, tw, tile, b, fc);
+    if (valid) {
+        uint64_t *o = A.out + ((inst * A.nodes_out + node) * K1 + p_own) * FHE_N;
+#pragma unroll
+        for (int a = 0; a < 16; ++a) {
+            o[16 * a + b] = c0lo[a] + torus_from_double(xr[a]);
+            o[256 + 16 * a + b] = c0hi[a] + torus_from_double(xi[a]);
         }
     }
 }

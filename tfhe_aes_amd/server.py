@@ -23,11 +23,11 @@ from .params import WopbsParameters
 
 
 def gen_lut(message_mod: int, carry_mod: int, poly_size: int, nb_block: int, f) -> np.ndarray:
-    """gen_lut.rs:9-42.  Returns [nb_block][poly_size] uint64, entry = output bit << 63."""
+    """gen_lut.rs:9-42.  Returns [nb_block][max(2^nb_block, poly_size)] uint64 (gen_lut.rs:19-23), entry = output bit << 63."""
     if message_mod != 2 or carry_mod != 1:
         raise ValueError("the path uses message_modulus 2, carry_modulus 1 (client.rs:53-54)")
-    if poly_size != 512 or not 1 <= nb_block <= 9:
-        raise ValueError("polynomial_size must be 512 and nb_block in 1..9")
+    if poly_size != 512 or not 1 <= nb_block <= 16:
+        raise ValueError("polynomial_size must be 512 and nb_block in 1..16")
     table = np.array([int(f(x)) for x in range(1 << nb_block)], dtype=np.uint64)
     return _native.gen_lut(nb_block, table)
 
@@ -64,8 +64,9 @@ class Server:
 
     # ---- S-Box front end --------------------------------------------------------
     def many_wopbs_without_padding(self, ct_in, luts):
-        """many_wopbs.rs:31: ct_in [n][bits][kN+1]; luts: list of gen_lut tables [bits][512] (shared by
-        all inputs) or an array [n][n_luts][bits][512] (one set per input).  Returns [n][n_luts][bits][kN+1]."""
+        """many_wopbs.rs:31: ct_in [n][bits][kN+1]; luts: list of gen_lut tables [bits][W] (shared by all inputs) or an array
+        [n][n_luts][bits][W] (one set per input), W = max(2^bits, 512).  Returns [n][n_luts][bits][kN+1].  The AES path uses
+        bits = 8 and 9; wider inputs (up to 16 bits) go through the CMUX tree of vertical_packing first."""
         n, bits = int(ct_in.shape[0]), int(ct_in.shape[1])
         if isinstance(luts, (list, tuple)):
             lut_arr = np.stack([np.asarray(l, dtype=np.uint64) for l in luts])[None]
@@ -76,7 +77,7 @@ class Server:
             if lut_arr.ndim == 3:
                 lut_arr = lut_arr[None]
         n_luts = int(lut_arr.shape[1])
-        if int(lut_arr.shape[2]) != bits or int(lut_arr.shape[3]) != 512:
+        if int(lut_arr.shape[2]) != bits or int(lut_arr.shape[3]) != max(512, 1 << bits):
             raise ValueError("LUT shape does not match the input radix width")
         lut_dev = _to_space(lut_arr, ct_in) if isinstance(lut_arr, np.ndarray) else lut_arr
         out = _empty_like(ct_in, (n, n_luts, bits, self.params.big1))
