@@ -117,6 +117,10 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo lets several ranks share one GPU to rehearse the N>1 path on a 1-GPU box")
+    ap.add_argument("--rccl-one-rank", action="store_true",
+                    help="at N=1 only: initialise the nccl (= RCCL) process group with ONE rank anyway and push the key and round-key "
+                         "broadcasts and the elapsed-time all-reduce through it (reported as rccl_one_rank); a builder's box has one GPU, "
+                         "so this is the only RCCL code a builder can run on hardware")
     ap.add_argument("--decrypt", action="store_true", help="time Server::aes_decrypt (BASELINE configs[4] path) instead of aes_encrypt")
     ap.add_argument("--no-ctr-iteration", action="store_true",
                     help="skip the extra (untimed-step) measurement of the reference's whole CTR iteration that the default line reports at N=1")
@@ -156,6 +160,17 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    rccl1 = None
+    if world == 1 and args.rccl_one_rank:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        t0 = time.time()
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                      # the first collective creates the communicator
+        torch.cuda.synchronize()
+        rccl1 = {"init_and_first_all_reduce_s": round(time.time() - t0, 3), "ranks": 1}
+
     # ---- keys: generated on rank 0, broadcast once over RCCL/xGMI --------------------------------
     client = Client(args.blocks * world, IV, KEY, params=p, seed=0xAE50001)     # secret keys: same seed on every rank
     t0 = time.time()
@@ -169,6 +184,15 @@ def main():
     torch.cuda.synchronize()
     bcast_s = time.time() - t0
     key_bytes_moved = sum(int(t.numel()) * 8 for t in dbodies) + 32
+    if rccl1 is not None:                           # the same tensors through a one-rank RCCL broadcast (dist.py skips it at world 1)
+        t0 = time.time()
+        sums = [int(t.sum().item()) for t in dbodies]
+        for t in dbodies:
+            dist.broadcast(t, src=0)
+        torch.cuda.synchronize()
+        rccl1["key_broadcast_s"] = round(time.time() - t0, 3)
+        rccl1["key_broadcast_bytes"] = key_bytes_moved - 32
+        rccl1["key_broadcast_intact"] = sums == [int(t.sum().item()) for t in dbodies]
     eng = _native.Engine(p, device=dev_index)
     t0 = time.time()
     eng.upload_keys_seeded(mask_seed, *dbodies)
@@ -233,9 +257,11 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_enable(False)
-    if world > 1:
+    if world > 1 or rccl1 is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        if rccl1 is not None:
+            rccl1["elapsed_all_reduce_max_ok"] = float(tt.item()) == elapsed
         elapsed = float(tt.item())
 
     # ---- CPU baseline (rank 0, outside the timed region; the other ranks wait at the final barrier) -----------------
@@ -352,11 +378,15 @@ def main():
                         "key_bytes_moved": key_bytes_moved, "key_expand_and_convert_on_gpu": round(expand_s, 3),
                         "aes_key_expansion": None if keyexp_s is None else round(keyexp_s, 3)},
         }
+        if rccl1 is not None:
+            rccl1["note"] = ("torch.distributed backend nccl (= RCCL) with world_size 1 on this GPU: communicator creation, the key broadcasts "
+                             "and the MAX all-reduce ran through RCCL; no second GPU, so no xGMI transfer took place")
+            line["rccl_one_rank"] = rccl1
         if cpu is not None:
             line["cpu_baseline"] = cpu
             line["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or rccl1 is not None:
         dist.barrier()
         dist.destroy_process_group()
 

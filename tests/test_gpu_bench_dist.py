@@ -47,6 +47,24 @@ def test_bench_two_ranks_gloo():
     assert "key_broadcast_gloo" in line["setup_s"]
 
 
+def test_bench_one_rank_through_rccl():
+    """the only RCCL code a one-GPU box can run: bench.py --rccl-one-rank initialises the nccl backend with one rank and pushes the
+    key broadcasts and the elapsed-time all-reduce through it (communicator creation + collectives on the MI355X; no xGMI transfer)"""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = str(_free_port())
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--params", "toy", "--blocks", "2", "--steps", "1", "--warmup", "0",
+                          "--rccl-one-rank", "--no-cpu-baseline", "--no-ctr-iteration"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    r = line["rccl_one_rank"]
+    assert r["ranks"] == 1 and r["key_broadcast_intact"] is True and r["elapsed_all_reduce_max_ok"] is True
+    assert line["n_gpus"] == 1 and line["verified_vs_aes"] is True
+
+
 def test_bench_refuses_world_size_mismatch():
     """--gpus must equal WORLD_SIZE: a silent single-rank run of a "2 GPU" bench would be an invalid number"""
     res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--params", "toy", "--blocks", "1"], cwd=str(ROOT),

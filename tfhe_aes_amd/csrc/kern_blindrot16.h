@@ -26,6 +26,9 @@
 #ifndef BR16_MAC_PRIO
 #define BR16_MAC_PRIO 0
 #endif
+#ifndef BR16_PARK_NT
+#define BR16_PARK_NT 0     /* nontemporal parking stores/loads (measured: see DESIGN.md) */
+#endif
 #define BR16_PARK_WORDS_PER_WG (16 * EP_THREADS * 2 * 2)   /* 16 chunks of 32 bytes per thread: lo[a], hi[a] pairs */
 
 __device__ __forceinline__ int br16_opaque_tid()
@@ -118,7 +121,16 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
                 stage[256 + 16 * a + bq_] = hi[a];
             }
 #pragma unroll
-            for (int a = 0; a < 16; ++a) { ulonglong2 v; v.x = lo[a]; v.y = hi[a]; (park + a * EP_THREADS)[(unsigned)tq] = v; }
+            for (int a = 0; a < 16; ++a) {
+                ulonglong2 v; v.x = lo[a]; v.y = hi[a];
+#if BR16_PARK_NT
+                typedef unsigned long long br16_u64x2 __attribute__((ext_vector_type(2)));
+                br16_u64x2 nv; nv[0] = v.x; nv[1] = v.y;
+                __builtin_nontemporal_store(nv, reinterpret_cast<br16_u64x2 *>(park + a * EP_THREADS) + (unsigned)tq);
+#else
+                (park + a * EP_THREADS)[(unsigned)tq] = v;
+#endif
+            }
             wave_lds_sync();
             fft_tw_load8(w0, psi, bq_, 16);                       // psi^(16a+b), a = 0..7: lands during the rotation
             __builtin_amdgcn_sched_barrier(0);
@@ -262,7 +274,15 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
         double *tile = lds + (tq >> 4) * GROUP_TILE_DOUBLES;
         ulonglong2 pk[16];
 #pragma unroll
-        for (int a = 0; a < 16; ++a) pk[a] = (park + a * EP_THREADS)[(unsigned)tq];
+        for (int a = 0; a < 16; ++a) {
+#if BR16_PARK_NT
+            typedef unsigned long long br16_u64x2 __attribute__((ext_vector_type(2)));
+            br16_u64x2 nv = __builtin_nontemporal_load(reinterpret_cast<const br16_u64x2 *>(park + a * EP_THREADS) + (unsigned)tq);
+            pk[a].x = nv[0]; pk[a].y = nv[1];
+#else
+            pk[a] = (park + a * EP_THREADS)[(unsigned)tq];
+#endif
+        }
         // ---- products back to the owning groups, inverse transform, accumulate --------------------------------------
         wg_barrier_lds_only();       // every thread is done reading the last level's digits from the tiles
 #pragma unroll

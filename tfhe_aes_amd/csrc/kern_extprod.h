@@ -67,9 +67,12 @@ struct ExtProdArgs {
 // One 16-byte key element through a raw buffer load: the address is (buffer base, scalar) + (row offset, scalar) +
 // (16 * point, the only vector part), so a key fetch costs no vector address arithmetic at all.
 typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
+#ifndef EP_KEY_AUX
+#define EP_KEY_AUX 0       /* cache policy bits of the key loads (1 = sc0, 2 = nt, 16 = sc1) */
+#endif
 __device__ __forceinline__ double2 ep_key_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane_bytes, unsigned row_bytes)
 {
-    ep_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, row_bytes, 0);
+    ep_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, row_bytes, EP_KEY_AUX);
     double2 d;
     d.x = __longlong_as_double((long long)(((unsigned long long)v[1] << 32) | v[0]));
     d.y = __longlong_as_double((long long)(((unsigned long long)v[3] << 32) | v[2]));

@@ -21,6 +21,9 @@ VARIANTS = {
     "old16": ["-DPBS_FORM16=0"],
     "form32": ["-DPBS_FORM32=1"],
     "b16_prio0": ["-DBR16_MAC_PRIO=0"],
+    "aux1": ["-DEP_KEY_AUX=1"], "aux2": ["-DEP_KEY_AUX=2"], "aux16": ["-DEP_KEY_AUX=16"], "aux17": ["-DEP_KEY_AUX=17"],
+    "aux18": ["-DEP_KEY_AUX=18"], "aux3": ["-DEP_KEY_AUX=3"], "aux19": ["-DEP_KEY_AUX=19"],
+    "parknt": ["-DBR16_PARK_NT=1"], "parknt_aux2": ["-DBR16_PARK_NT=1", "-DEP_KEY_AUX=2"],
     "stag8_1": ["-DBR16_STAGGER_SHIFT=8", "-DBR16_STAGGER_SLEEP=1"],
     "stag8_2": ["-DBR16_STAGGER_SHIFT=8", "-DBR16_STAGGER_SLEEP=2"],
     "stag8_4": ["-DBR16_STAGGER_SHIFT=8", "-DBR16_STAGGER_SLEEP=4"],
