@@ -45,8 +45,10 @@ __device__ __forceinline__ void cmulc(double &xr, double &xi, double wr, double 
 
 // DFT of length 16 in registers, radix-2 DIF, natural-order output.
 // INV = false: kernel e^{+2 pi i a k / 16}; INV = true: conjugate kernel.
-template <bool INV>
-__device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], const FftConsts fc)
+// `hook(stage)` runs after butterfly stage 0..3 (a caller interleaves independent memory instructions there).
+struct FftNoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <bool INV, typename Hook = FftNoHook>
+__device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], const FftConsts fc, Hook hook = Hook())
 {
 #pragma unroll
     for (int half = 8; half >= 1; half >>= 1) {
@@ -77,6 +79,7 @@ __device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], const 
                 }
             }
         }
+        hook(half == 8 ? 0 : half == 4 ? 1 : half == 2 ? 2 : 3);
     }
     // bit-reversal to natural order (compile-time register renaming)
 #define FFT_SWAP(i, j) { double t0 = xr[i]; xr[i] = xr[j]; xr[j] = t0; double t1 = xi[i]; xi[i] = xi[j]; xi[j] = t1; }

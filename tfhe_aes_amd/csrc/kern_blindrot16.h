@@ -14,8 +14,11 @@
 //    parking frees hold two 8-entry twiddle buffers; table reads are issued a whole batch (and a whole DFT16 or
 //    decomposition step) ahead of their use.  The transformed digits of the next multiply-accumulate row are read
 //    one row ahead the same way.
-//  * all 25 GGSW entries of a level are requested right after the digit stores, into the registers the transform
-//    working set and the twiddle buffers have just left (100 of 128), before the exchange barrier.
+//  * a burst of 25 key loads blocks the in-order wave for as long as the L1 takes to accept them (~150 cycles each with one
+//    workgroup on the CU: 28 % of a lone wave's time).  15 of the 25 GGSW entries of a level are therefore requested one or two
+//    at a time BETWEEN the instructions of the transpose and of the second DFT16, into the registers the twiddle buffers have
+//    just left; the other 10 right after the digit stores, into the registers of the transform working set, before the
+//    exchange barrier.
 //  * key rows are addressed as (scalar row pointer) + (16 * point) so no 64-bit vector address arithmetic is issued;
 //    LDS addresses are (one base per lane) + constants, recomputed per phase from an opaque lane index so the
 //    compiler does not keep dozens of them live across the 669-iteration loop.
@@ -25,6 +28,12 @@
 
 #ifndef BR16_MAC_PRIO
 #define BR16_MAC_PRIO 0
+#endif
+#ifndef BR16_EARLY
+#define BR16_EARLY 15      /* GGSW entries (of 25 per level; scaled to K1*K1) requested between the instructions of the transform's
+                              second half.  Measured at 16,384 bits: 0 -> 267 ms, 12 -> 267, 13 -> 255, 14 -> 253, 15 -> 251.5, 16 -> 263,
+                              20 -> 268, 25 -> 297 (spills past 18); some of them ahead of the tiles-free barrier, or the late ones
+                              between the digit stores: no gain. */
 #endif
 #ifndef BR16_PARK_NT
 #define BR16_PARK_NT 0     /* nontemporal parking stores/loads (measured: see DESIGN.md) */
@@ -181,35 +190,71 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
 #pragma unroll
             for (int k = 1; k < 8; ++k) cmul(xr[8 + k], xi[8 + k], w1[k].x, w1[k].y);
             EP_STAMP(2);
+            const unsigned gl_bytes = g_bytes + (unsigned)l * (K1 * K1 * FHE_H * 16);   // scalar; the lane adds 16 * point
+            double2 bm[K1][K1];
+            // GGSW entries [from, to) of this level (row-major: the multiply-accumulate consumes them in this order)
+            auto key_rows = [&](const int from, const int to) {
+#pragma unroll
+                for (int q = 0; q < K1 * K1; ++q) {
+                    if (q < from || q >= to) continue;
+#ifdef BR16_ABL_NOLOAD
+                    bm[q / K1][q % K1] = make_double2((double)(tq + q), (double)(tq - q));
+#else
+                    bm[q / K1][q % K1] = ep_key_load(bsk_rsrc, (unsigned)tq * 16u, gl_bytes + (unsigned)q * (FHE_H * 16));
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            // The first BR16_EARLY entries are requested a few at a time BETWEEN the instructions of the transpose and of the
+            // second DFT16, into the registers the twiddle buffers have just left: a burst of 25 loads blocks the in-order
+            // wave for as long as the L1 takes to accept them (~150 cycles each with one workgroup per CU); spaced out,
+            // the same acceptance time passes under the wave's own LDS and vector work.
+            constexpr int NE = BR16_EARLY * K1 * K1 / 25, NHOOK = 7;
+            auto early = [&](const int h) { key_rows(NE * h / NHOOK, NE * (h + 1) / NHOOK); };
             if (tiles_busy) wg_barrier_lds_only();                // every thread is done reading the previous level's digits
             EP_STAMP(3);
 #if defined(BR16_ABL_NOFFT)
             group_transpose(xr, xi, tile, bq_);
+            key_rows(0, NE);
 #elif defined(BR16_ABL_NOXPOSE)
             dft16<false>(xr, xi, fc);
+            key_rows(0, NE);
 #else
-            nega_fwd_tail(xr, xi, tile, bq_, fc);
+            {
+#if FFT_XPOSE_PRIO
+                __builtin_amdgcn_s_setprio(FFT_XPOSE_PRIO);
+#endif
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1) {
+                    double2 v; v.x = xr[k1]; v.y = xi[k1];
+                    *reinterpret_cast<double2 *>(tile + 2 * (k1 * 17 + bq_)) = v;
+                    if (NE && k1 == 7) { __builtin_amdgcn_sched_barrier(0); early(0); }
+                }
+                if (NE) { __builtin_amdgcn_sched_barrier(0); early(1); }
+                wave_lds_sync();
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
+                    xr[c] = v.x; xi[c] = v.y;
+                }
+                if (NE) { __builtin_amdgcn_sched_barrier(0); early(2); }
+                wave_lds_sync();
+#if FFT_XPOSE_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                dft16<false>(xr, xi, fc, [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } });
+            }
 #endif
             EP_STAMP(4);
-            // store the transformed digits, then request all K1 x K1 GGSW entries of this level into the registers the
-            // working set and the twiddle buffers have just left
+            // store the transformed digits, then request the remaining GGSW entries of this level into the registers the
+            // working set has just left
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 double2 v; v.x = xr[k2]; v.y = xi[k2];
                 *reinterpret_cast<double2 *>(tile + 2 * (bq_ + 16 * k2)) = v;
             }
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned gl_bytes = g_bytes + (unsigned)l * (K1 * K1 * FHE_H * 16);   // scalar; the lane adds 16 * point
-            double2 bm[K1][K1];
-#pragma unroll
-            for (int p = 0; p < K1; ++p)
-#pragma unroll
-#ifdef BR16_ABL_NOLOAD
-                for (int c = 0; c < K1; ++c) bm[p][c] = make_double2((double)(tq + c + p), (double)(tq - c));
-#else
-                for (int c = 0; c < K1; ++c) bm[p][c] = ep_key_load(bsk_rsrc, (unsigned)tq * 16u, gl_bytes + (unsigned)(p * K1 + c) * (FHE_H * 16));
-#endif
-            __builtin_amdgcn_sched_barrier(0);
+            key_rows(NE, K1 * K1);
             EP_STAMP(5);
             wg_barrier_lds_only();                                // digits of all groups visible; key loads stay in flight
             EP_STAMP(6);

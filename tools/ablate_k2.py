@@ -21,6 +21,12 @@ VARIANTS = {
     "old16": ["-DPBS_FORM16=0"],
     "form32": ["-DPBS_FORM32=1"],
     "b16_prio0": ["-DBR16_MAC_PRIO=0"],
+    "e0": ["-DBR16_EARLY=0"], "e4": ["-DBR16_EARLY=4"], "e8": ["-DBR16_EARLY=8"], "e12": ["-DBR16_EARLY=12"], "e14": ["-DBR16_EARLY=14"],
+    "e16": ["-DBR16_EARLY=16"], "e20": ["-DBR16_EARLY=20"], "e25": ["-DBR16_EARLY=25"],
+    "e12_stamps": ["-DBR16_EARLY=12", "-DEP_STAMPS"], "e12_one_wg": ["-DBR16_EARLY=12", "-DBR16_PAD_DOUBLES=2048"],
+    "e13": ["-DBR16_EARLY=13"], "e15": ["-DBR16_EARLY=15"], "e10": ["-DBR16_EARLY=10"], "e18": ["-DBR16_EARLY=18"],
+    "e14_stamps": ["-DBR16_EARLY=14", "-DEP_STAMPS"], "e15_stamps": ["-DBR16_EARLY=15", "-DEP_STAMPS"],
+    "e15_one_wg_stamps": ["-DBR16_EARLY=15", "-DEP_STAMPS", "-DBR16_PAD_DOUBLES=2048"], "e15_one_wg": ["-DBR16_EARLY=15", "-DBR16_PAD_DOUBLES=2048"],
     "aux1": ["-DEP_KEY_AUX=1"], "aux2": ["-DEP_KEY_AUX=2"], "aux16": ["-DEP_KEY_AUX=16"], "aux17": ["-DEP_KEY_AUX=17"],
     "aux18": ["-DEP_KEY_AUX=18"], "aux3": ["-DEP_KEY_AUX=3"], "aux19": ["-DEP_KEY_AUX=19"],
     "parknt": ["-DBR16_PARK_NT=1"], "parknt_aux2": ["-DBR16_PARK_NT=1", "-DEP_KEY_AUX=2"],
