@@ -96,9 +96,12 @@ def main():
     rng = np.random.default_rng(0)
     small = rng.integers(0, 1 << 64, (M, p.n + 1), dtype=np.uint64)
     for name in names:
-        so = out / ("libfheaes_%s.so" % name)
-        cmd = [_build.hipcc_path()] + _build.engine_flags() + VARIANTS[name] + ["-o", str(so), str(_build.ENGINE_SOURCES[0])]
-        subprocess.run(cmd, check=True, capture_output=True)
+        if name.startswith("so:"):                      # an already built library (A/B against an older build on the same box)
+            so = Path(name[3:])
+        else:
+            so = out / ("libfheaes_%s.so" % name)
+            cmd = [_build.hipcc_path()] + _build.engine_flags() + VARIANTS[name] + ["-o", str(so), str(_build.ENGINE_SOURCES[0])]
+            subprocess.run(cmd, check=True, capture_output=True)
         lib = ctypes.CDLL(str(so))
         for fn, (res, args) in _native.SIGNATURES.items():
             f = getattr(lib, fn)
