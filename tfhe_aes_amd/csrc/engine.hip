@@ -312,8 +312,8 @@ struct StageScope {
 #ifdef EP_STAMPS
 // developer build: per-phase cycle counts written by the blind-rotation kernels
 struct StampReport {
-    fheaes_ctx *c; unsigned long long *d = nullptr; size_t waves; const char *const *names;
-    StampReport(fheaes_ctx *ctx, size_t waves_, const char *const *names_) : c(ctx), waves(waves_), names(names_)
+    fheaes_ctx *c; unsigned long long *d = nullptr; size_t waves; const char *const *names; int per_wg;
+    StampReport(fheaes_ctx *ctx, size_t waves_, const char *const *names_, int per_wg_ = 0) : c(ctx), waves(waves_), names(names_), per_wg(per_wg_)
     {
         (void)hipMalloc((void **)&d, waves * EP_NPH * 8);
         (void)hipMemsetAsync(d, 0, waves * EP_NPH * 8, c->stream);
@@ -330,6 +330,20 @@ struct StampReport {
         fprintf(stderr, "K2 phase cycles per wave per iteration (s_memtime ticks, avg over %zu waves):\n", waves);
         for (int i = 0; i < EP_NPH; ++i) fprintf(stderr, "  %-32s %9.0f  %5.1f %%\n", names[i], tot[i] / ((double)waves * c->n), 100.0 * tot[i] / all);
         fprintf(stderr, "  %-32s %9.0f\n", "total", all / ((double)waves * c->n));
+        if (per_wg) {                                   // the same per wave slot of a workgroup (who is the slowest at each barrier)
+            fprintf(stderr, "  per wave of a workgroup:      ");
+            for (int w = 0; w < per_wg; ++w) fprintf(stderr, " %7d", w);
+            fprintf(stderr, "\n");
+            for (int i = 0; i < EP_NPH; ++i) {
+                fprintf(stderr, "  %-30s", names[i]);
+                for (int w = 0; w < per_wg; ++w) {
+                    double t = 0;
+                    for (size_t g = w; g < waves; g += per_wg) t += (double)h[g * EP_NPH + i];
+                    fprintf(stderr, " %7.0f", t / ((double)(waves / per_wg) * c->n));
+                }
+                fprintf(stderr, "\n");
+            }
+        }
     }
 };
 #endif
@@ -412,9 +426,9 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
     if (m <= LATENCY_BATCH_BITS) {
         // latency regime: one ciphertext per 512-thread workgroup, all levels transformed at once (kern_blindrot_latency.h)
 #ifdef EP_STAMPS
-        static const char *namesL[EP_NPH] = {"top: key loads issued", "rotate+decompose", "forward fft", "digit stores", "barrier (digits)", "MAC", "barrier (MAC done)",
-                                             "products store", "barrier (products)", "inverse fft + accumulate", "barrier (acc)", "-"};
-        StampReport rep(c, (size_t)m * 8, namesL);
+        static const char *namesL[EP_NPH] = {"barrier (result) + accumulate", "rotate+decompose (1 coeff x K1)", "read digits + forward fft", "digit stores", "barrier (digits)", "MAC", "barrier (MAC done)",
+                                             "products store + next rows", "barrier (products)", "inverse fft -> doubles", "barrier (acc)", "barrier (decomposition)"};
+        StampReport rep(c, (size_t)m * 8, namesL, 8);
         a.stamps = rep.d;
 #endif
         if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate_latency_kernel<5, 5, 8>), dim3((unsigned)m), dim3(BL_THREADS), 0, c->stream, a);

@@ -4,10 +4,11 @@
 // ciphertexts fit a workgroup; with at most a few hundred bits in flight the GPU is mostly empty and what counts
 // is the length of the dependent chain of one iteration.  Here ONE ciphertext owns a 512-thread workgroup and all
 // L x K1 digit polynomials of an iteration are transformed at once:
-//   LDS                     the accumulator (K1 x 512 torus words) LIVES here: read rotated and unrotated by the digit
-//                           groups, updated in place by the owner groups at the end of the iteration;
-//   groups 0..L*K1-1        group (l, p) rebuilds d_p = acc_p * X^t - acc_p from LDS, peels the decomposition down
-//                           to its level l and transforms that digit polynomial into tile (l, p);
+//   LDS                     the accumulator (K1 x 512 torus words) LIVES here, updated in place by the owner groups at the
+//                           end of the iteration;
+//   all 512 threads         thread j rebuilds coefficient j of d_p = acc_p * X^t - acc_p for every p, decomposes it once and
+//                           writes the L digits into the tiles of the L x K1 digit polynomials;
+//   groups 0..L*K1-1        group (l, p) transforms its digit polynomial in tile (l, p);
 //   all 512 threads         multiply-accumulate: thread = (Fourier point, share of the K1 output columns); the whole
 //                           L*K1-row chain (same order as everywhere: least significant level first, rows ascending);
 //   groups 0..K1-1          inverse transform of output polynomial c, accumulate into LDS.
@@ -47,10 +48,9 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
     const int tid = threadIdx.x;
     const int g = tid >> 4, b = tid & 15;
     const bool transform = g < ROWS;                  // group (l_idx, p): row index g = k*K1 + p, k = 0 is the least significant level
-    const int kk = transform ? g / K1 : 0;            // how many levels to peel before ours
-    const int p_own = transform ? g % K1 : 0;
     const bool owner = g < K1;                        // output polynomial g is inverse-transformed by this group
-    const bool half_b = tid >= 256;                   // multiply-accumulate role: columns CA..K1-1 (wave-uniform)
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: what depends on it stays in SGPRs / scalar branches
+    const bool half_b = wave_id >= 4;                 // multiply-accumulate role: columns CA..K1-1 (wave-uniform)
     const FftConsts fc = A.fc;
 
     if (tid < FHE_H) {
@@ -86,33 +86,60 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
 #endif
 
     unsigned pf_sink = 0;
+    // One level of GGSW rows in flight per thread: (Fourier point tid mod 256) x (this half's share of the columns).  The rows of
+    // the first level of iteration it+1 do not depend on data: they are requested at the end of iteration it (and here for it = 0).
+    double2 bq[K1][CA];
+    const unsigned col_bytes = half_b ? (unsigned)CA * (FHE_H * 16) : 0u;      // wave-uniform
+    auto load_row = [&](unsigned gb, unsigned mp_, int k, int p, double2 (&dst)[CA]) {
+#pragma unroll
+        for (int c = 0; c < CA; ++c)
+            if (c < CB || !half_b) dst[c] = ep_key_load(bsk_rsrc, mp_ * 16u, gb + row_bytes(k, p) + col_bytes + (unsigned)c * (FHE_H * 16));
+    };
+#pragma unroll
+    for (int p = 0; p < K1; ++p) load_row(0u, (unsigned)(tid & 255), 0, p, bq[p]);
     for (uint32_t it = 0; it < A.iters; ++it) {
         const int t = mod_switch_1024(a_next);
         a_next = lwe[it + 1];                          // one iteration ahead (the last one reads the body: unused)
 #ifdef BL_ABL_SAMEKEY
-        const unsigned g_bytes = 0;                    // developer ablation (wrong results): every iteration reads GGSW 0, L2-resident
+        const unsigned g_bytes = 0, g_next = 0;        // developer ablation (wrong results): every iteration reads GGSW 0, L2-resident
 #else
-        const unsigned g_bytes = it * GGSW_BYTES;
+        const unsigned g_bytes = it * GGSW_BYTES, g_next = g_bytes + GGSW_BYTES;
 #endif
         int tq = tid;
         asm volatile("" : "+v"(tq));                   // addresses below are recomputed from this, not kept across iterations
         const int bq_ = tq & 15, mp = tq & 255;
         double *tile = lds + (transform ? (tq >> 4) : 0) * GROUP_TILE_DOUBLES;
 
-        // ---- 0. the first rows of this iteration's multiply-accumulate: no data dependence, request them now ----------
-        double2 bq[K1][CA];                            // one level of rows in flight
-        const unsigned col_bytes = half_b ? (unsigned)CA * (FHE_H * 16) : 0u;      // wave-uniform
-        auto load_row = [&](int k, int p, double2 (&dst)[CA]) {
+        // ---- 1a. d = acc * X^t - acc and its gadget decomposition, ONCE per coefficient: thread j owns coefficient j of every
+        //      polynomial and writes the L digits (as doubles) into the tiles of the (level, polynomial) groups that transform
+        //      them.  (Round-2 first form: each of the L groups of a polynomial rebuilt d and peeled down to its own level -- five
+        //      times the integer work, and the deepest groups set the length of the iteration.)
+        {
+            const int s0 = (tq - t) & 511;
+            const bool neg = ((s0 + t) >> 9) & 1;
+            uint64_t rv[K1], ra[K1];
 #pragma unroll
-            for (int c = 0; c < CA; ++c)
-                if (c < CB || !half_b) dst[c] = ep_key_load(bsk_rsrc, (unsigned)mp * 16u, g_bytes + row_bytes(k, p) + col_bytes + (unsigned)c * (FHE_H * 16));
-        };
+            for (int p = 0; p < K1; ++p) { rv[p] = accs[p * FHE_N + s0]; ra[p] = accs[p * FHE_N + tq]; }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < K1; ++p) load_row(0, p, bq[p]);
-        EP_STAMP(0);
-
+            for (int p = 0; p < K1; ++p) {
+                uint64_t v = rv[p];
+                if (neg) v = (uint64_t)0 - v;
+                v -= ra[p];
+                uint32_t st;
+                int d = decompose_first<BASE_LOG, LEVELS>(v, st);
+#pragma unroll
+                for (int k = 0; k < LEVELS; ++k) {
+                    if (k) d = decompose_next<BASE_LOG>(st);
+                    lds[(k * K1 + p) * GROUP_TILE_DOUBLES + tq] = (double)d;
+                }
+            }
+        }
+        EP_STAMP(1);
+        wg_barrier_lds_only();                         // digits of every level in place
+        EP_STAMP(11);
 #if BL_L2_PREFETCH
-        // ---- 0b. the last wave holds no digit polynomial and would only wait at the barrier: it walks the NEXT iteration's
+        // ---- 1c. the last wave holds no digit polynomial and would only wait at the next barrier: it walks the NEXT iteration's
         //      GGSW (one dword per 128-byte line) so that the 512 KB come from HBM into this XCD's L2 an iteration ahead of
         //      their use; in a small batch every workgroup is at the same iteration and the first touch of a GGSW is otherwise a
         //      DRAM round trip on the multiply-accumulate's critical path.  Workgroups are dealt to the 8 XCDs round-robin, so
@@ -127,30 +154,14 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
             pf_sink ^= sink;
         }
 #endif
-        // ---- 1. every (level, polynomial) group: rotate, subtract, peel to its level, transform -----------------------
+        // ---- 1b. every (level, polynomial) group transforms its digit polynomial ------------------------------------------
         if (transform) {
-            const uint64_t *src = accs + (size_t)p_own * FHE_N;
             double xr[16], xi[16];
             double2 w0[8], w1[8];
-            fft_tw_load8(w0, psi, bq_, 16);            // lands during the rotation
+            fft_tw_load8(w0, psi, bq_, 16);
 #pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                int j0 = 16 * a + bq_;
-                int s0 = (j0 - t) & 511, s1 = s0 ^ 256;
-                uint64_t v0 = src[s0], v1 = src[s1];
-                if (((s0 + t) >> 9) & 1) v0 = (uint64_t)0 - v0;
-                if (((s1 + t) >> 9) & 1) v1 = (uint64_t)0 - v1;
-                v0 -= src[j0]; v1 -= src[j0 + 256];
-                uint32_t s_lo, s_hi;
-                int d0 = decompose_first<BASE_LOG, LEVELS>(v0, s_lo);
-                int d1 = decompose_first<BASE_LOG, LEVELS>(v1, s_hi);
-                for (int q = 0; q < kk; ++q) {        // wave-divergent trip count only between groups of different level
-                    d0 = decompose_next<BASE_LOG>(s_lo);
-                    d1 = decompose_next<BASE_LOG>(s_hi);
-                }
-                xr[a] = (double)d0; xi[a] = (double)d1;
-            }
-            EP_STAMP(1);
+            for (int a = 0; a < 16; ++a) { xr[a] = tile[16 * a + bq_]; xi[a] = tile[256 + 16 * a + bq_]; }
+            wave_lds_sync();                           // the group's lanes have their coefficients before the transform reuses the tile
             nega_fwd_batched(xr, xi, w0, w1, psi, tw, tile, bq_, fc);
             EP_STAMP(2);
 #pragma unroll
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
                 double2 bv[CA];
 #pragma unroll
                 for (int c = 0; c < CA; ++c) bv[c] = bq[p][c];
-                if (k + 1 < LEVELS) load_row(k + 1, p, bq[p]);               // the same row of the next level, one level ahead
+                if (k + 1 < LEVELS) load_row(g_bytes, (unsigned)mp, k + 1, p, bq[p]);      // the same row of the next level, one level ahead
                 const double2 d = dn;
                 if (p + 1 < K1) dn = *reinterpret_cast<const double2 *>(dl + (p + 1) * GROUP_TILE_DOUBLES);
                 __builtin_amdgcn_sched_barrier(0);
@@ -201,10 +212,17 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
                 *reinterpret_cast<double2 *>(lds + ((half_b ? CA : 0) + c) * GROUP_TILE_DOUBLES + 2 * mp) = v;
             }
         }
+        // the first level's rows of the NEXT iteration: every row register is free again
+        if (it + 1 < A.iters) {
+#pragma unroll
+            for (int p = 0; p < K1; ++p) load_row(g_next, (unsigned)mp, 0, p, bq[p]);
+        }
         EP_STAMP(7);
         wg_barrier_lds_only();
         EP_STAMP(8);
-        // ---- 3. owner groups: inverse transform of output polynomial g, accumulate into the LDS accumulator ------------
+        // ---- 3. owner groups: inverse transform of output polynomial g; the result (still doubles) goes back to the tile in
+        //      coefficient order.  Conversion to the torus and the accumulate are spread over all 512 threads below (on the five
+        //      owner groups alone they were a third of this phase, with everyone else waiting).
         if (owner) {
             double xr[16], xi[16];
             double2 w0[8], w1[8];
@@ -215,14 +233,16 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
             }
             wave_lds_sync();
             nega_inv_batched(xr, xi, w0, w1, psi, tw, tile, bq_, fc);
-            uint64_t *mine = accs + (size_t)(tq >> 4) * FHE_N + bq_;
+            wave_lds_sync();                           // the transform's last reads of the tile are done in every lane of the group
 #pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                mine[16 * a] += torus_from_double(xr[a]);
-                mine[256 + 16 * a] += torus_from_double(xi[a]);
-            }
+            for (int a = 0; a < 16; ++a) { tile[16 * a + bq_] = xr[a]; tile[256 + 16 * a + bq_] = xi[a]; }
         }
         EP_STAMP(9);
+        wg_barrier_lds_only();                         // results of all K1 polynomials in place
+        // ---- 4. all threads: thread j converts and accumulates coefficient j of every polynomial ------------------------
+#pragma unroll
+        for (int p = 0; p < K1; ++p) accs[p * FHE_N + tq] += torus_from_double(lds[p * GROUP_TILE_DOUBLES + tq]);
+        EP_STAMP(0);
         wg_barrier_lds_only();                         // accumulator complete before the next iteration's rotation reads it
         EP_STAMP(10);
     }
