@@ -139,19 +139,20 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
         wg_barrier_lds_only();                         // digits of every level in place
         EP_STAMP(11);
 #if BL_L2_PREFETCH
-        // ---- 1c. the last wave holds no digit polynomial and would only wait at the next barrier: it walks the NEXT iteration's
-        //      GGSW (one dword per 128-byte line) so that the 512 KB come from HBM into this XCD's L2 an iteration ahead of
-        //      their use; in a small batch every workgroup is at the same iteration and the first touch of a GGSW is otherwise a
-        //      DRAM round trip on the multiply-accumulate's critical path.  Workgroups are dealt to the 8 XCDs round-robin, so
-        //      the up to 16 workgroups of an XCD share the walk.
-        if (tid >= BL_THREADS - 64 && it + 1 < A.iters) {
-            const unsigned nshare = gridDim.x >= 128 ? 16u : gridDim.x >= 64 ? 8u : gridDim.x >= 32 ? 4u : gridDim.x >= 16 ? 2u : 1u;
+        // ---- 1c. in a small batch every workgroup is at the same iteration, so the first touch of a GGSW would be a DRAM round trip
+        //      on the multiply-accumulate's critical path.  The workgroups that share an XCD (dealt to the 8 XCDs round-robin) walk
+        //      the NEXT iteration's GGSW between them, one dword per 128-byte line, an iteration ahead of its use.  Nobody waits
+        //      for these loads: their values are folded into a dead sink after the multiply-accumulate, by when they have landed.
+        unsigned pf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pf[i] = 0;
+        if (it + 1 < A.iters) {
+            const unsigned nshare = gridDim.x >= 64 ? 8u : gridDim.x >= 32 ? 4u : gridDim.x >= 16 ? 2u : 1u;   // scalar
             const unsigned mine = (blockIdx.x >> 3) % nshare;
-            const unsigned lane = (unsigned)tid & 63u;
-            unsigned sink = 0;
-            for (unsigned line = mine + nshare * lane; line < GGSW_BYTES / 128; line += nshare * 64)
-                sink ^= __builtin_amdgcn_raw_buffer_load_b32(bsk_rsrc, line * 128u, g_bytes + GGSW_BYTES, 0);
-            pf_sink ^= sink;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if ((unsigned)i * nshare < 8u)
+                    pf[i] = __builtin_amdgcn_raw_buffer_load_b32(bsk_rsrc, (mine + nshare * ((unsigned)tq + 512u * i)) * 128u, g_next, 0);
         }
 #endif
         // ---- 1b. every (level, polynomial) group transforms its digit polynomial ------------------------------------------
@@ -202,6 +203,10 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#if BL_L2_PREFETCH
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pf_sink ^= pf[i];
+#endif
         EP_STAMP(5);
         wg_barrier_lds_only();                         // all digits consumed: tiles 0..K1-1 may take the products
         EP_STAMP(6);
