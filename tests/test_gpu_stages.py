@@ -39,9 +39,9 @@ def test_k1_keyswitch(which, m, request):
 @pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 8), ("toy", 21), ("toy", 300), ("toy", 530),
                                      ("opt", 1), ("opt", 7), ("opt", 300), ("opt", 520)])
 def test_k2_blind_rotation(which, m, request):
-    # every launch form of engine.hip::launch_cbs_pbs: m <= 256 the one-ciphertext-per-512-thread-workgroup latency kernel;
-    # 257..512 at k=4 the throughput kernel of kern_extprod.h with one ciphertext per workgroup; larger batches
-    # kern_blindrot16.h with 3 (k=4) or 8 (k=1) ciphertexts per workgroup
+    # every launch form of engine.hip::launch_cbs_pbs: m <= 256 the one-ciphertext-per-512-thread-workgroup latency kernel
+    # (1, 7/8/21 bits: every sharing degree of its L2 walk); larger batches kern_blindrot16.h with 3 (k=4) or 8 (k=1)
+    # ciphertexts per workgroup, below and above one workgroup per CU, ragged last workgroup
     kit = request.getfixturevalue(which)
     p, E = kit.params, kit.engine()
     x, bits = _inputs(kit, m, 20 + m)

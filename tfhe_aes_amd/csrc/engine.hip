@@ -31,9 +31,6 @@
 #define FHEAES_VERSION_STR "fheaes-mi355x 0.1 (gfx950)"
 #define MAX_CHUNK_BITS 32768ull
 #define MAX_WOPBS_BITS 16u            /* widest radix input of many_wopbs_without_padding (LUT of 2^16 entries per output bit) */
-#ifndef SMALL_BATCH_BITS
-#define SMALL_BATCH_BITS 512ull    /* at most 2 one-ciphertext workgroups per CU */
-#endif
 
 namespace {
 
@@ -433,10 +430,8 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
 #endif
         if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate_latency_kernel<5, 5, 8>), dim3((unsigned)m), dim3(BL_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((blind_rotate_latency_kernel<2, 5, 8>), dim3((unsigned)m), dim3(BL_THREADS), 0, c->stream, a);
-    } else if (c->k1 == 5 && m <= SMALL_BATCH_BITS) {
-        // latency regime (key expansion, counter add, one block): one ciphertext per workgroup spreads the batch
-        // over more CUs and shortens the multiply-accumulate of every iteration; same arithmetic, same bits
-        hipLaunchKernelGGL((extprod_rotate_kernel<5, 5, 8, 1, false>), dim3((unsigned)m), dim3(EP_THREADS), 0, c->stream, a);
+        // (257..768 bits: the throughput form below with at most one workgroup per CU, 14.6 ms per launch; the round-1
+        //  one-ciphertext-per-workgroup form of kern_extprod.h took 21.6 ms there and the latency form in two waves 16-18 ms)
 #if PBS_FORM32
     } else if (c->k1 == 5 || c->k1 == 2) {
         // throughput form: 32 lanes per polynomial, 4 waves per SIMD (kern_blindrot32.h)
