@@ -37,11 +37,11 @@ def test_k1_keyswitch(which, m, request):
 
 
 @pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 8), ("toy", 21), ("toy", 300), ("toy", 530),
-                                     ("opt", 1), ("opt", 7), ("opt", 300), ("opt", 520)])
+                                     ("opt", 1), ("opt", 7), ("opt", 300), ("opt", 520), ("opt", 800)])
 def test_k2_blind_rotation(which, m, request):
     # every launch form of engine.hip::launch_cbs_pbs: m <= 256 the one-ciphertext-per-512-thread-workgroup latency kernel
     # (1, 7/8/21 bits: every sharing degree of its L2 walk); larger batches kern_blindrot16.h with 3 (k=4) or 8 (k=1)
-    # ciphertexts per workgroup, below and above one workgroup per CU, ragged last workgroup
+    # ciphertexts per workgroup, below (opt 300, 520) and above (opt 800 = 267 workgroups) one workgroup per CU, ragged last one
     kit = request.getfixturevalue(which)
     p, E = kit.params, kit.engine()
     x, bits = _inputs(kit, m, 20 + m)
