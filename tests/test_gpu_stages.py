@@ -37,11 +37,12 @@ def test_k1_keyswitch(which, m, request):
 
 
 @pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 8), ("toy", 21), ("toy", 300), ("toy", 530),
-                                     ("opt", 1), ("opt", 7), ("opt", 300), ("opt", 520), ("opt", 800)])
+                                     ("opt", 1), ("opt", 7), ("opt", 300), ("opt", 520), ("opt", 800), ("opt", 2100)])
 def test_k2_blind_rotation(which, m, request):
     # every launch form of engine.hip::launch_cbs_pbs: m <= 256 the one-ciphertext-per-512-thread-workgroup latency kernel
     # (1, 7/8/21 bits: every sharing degree of its L2 walk); larger batches kern_blindrot16.h with 3 (k=4) or 8 (k=1)
-    # ciphertexts per workgroup, below (opt 300, 520) and above (opt 800 = 267 workgroups) one workgroup per CU, ragged last one
+    # ciphertexts per workgroup, below (opt 300, 520) and above (opt 800 = 267 workgroups) one workgroup per CU, ragged last one;
+    # opt 2100 = two full generations of 52 three-ciphertext and 972 two-ciphertext workgroups (the balanced launch)
     kit = request.getfixturevalue(which)
     p, E = kit.params, kit.engine()
     x, bits = _inputs(kit, m, 20 + m)

@@ -196,6 +196,7 @@ struct fheaes_ctx {
     std::recursive_mutex mu;
     // shapes
     uint32_t n = 0, k = 0, k1 = 0, big = 0, big1 = 0;
+    uint32_t cu_count = 256;             // compute units of the device (MI355X: 256)
     // keys
     int8_t *ksk_frag = nullptr, *pfpksk_frag = nullptr;      // balanced key bytes in MFMA B-fragment order
     uint32_t ks_ksteps = 0, ks_coltiles = 0, pf_ksteps = 0, pf_coltiles = 0;
@@ -455,7 +456,24 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
     } else {
         // throughput form (kern_blindrot16.h): accumulator parked in HBM between uses, key rows prefetched across the transform
         const unsigned R16 = c->k1 == 5 ? 3 : 8;
-        const unsigned grid16 = (unsigned)((m + R16 - 1) / R16);
+        unsigned grid16 = (unsigned)((m + R16 - 1) / R16);
+        a.units_main = grid16;
+#ifndef PBS_BALANCE
+#define PBS_BALANCE 1
+#endif
+        if (PBS_BALANCE && c->k1 == 5) {
+            // more units than slots (two workgroups per CU): a whole number of generations of 3- and 2-ciphertext units that
+            // cover the batch exactly, the 2-ciphertext ones last (see blind_rotate16_kernel)
+            const uint64_t slots = 2ull * c->cu_count;
+            if (grid16 > slots) {
+                const uint64_t nu = slots * ((m + 3 * slots - 1) / (3 * slots));
+                if (2 * nu <= m) {
+                    const uint64_t n2 = 3 * nu - m;
+                    a.units_main = (uint32_t)(nu - n2);
+                    grid16 = (unsigned)nu;
+                }
+            }
+        }
         TRY(ensure(c, c->ws_park, (size_t)grid16 * BR16_PARK_WORDS_PER_WG * 8));
         a.park = (uint64_t *)c->ws_park.p;
 #ifdef EP_STAMPS
@@ -464,7 +482,7 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         StampReport rep(c, (size_t)grid16 * 4, names16);
         a.stamps = rep.d;
 #endif
-        if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate16_kernel<5, 5, 8, 3>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
+        if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate16_kernel<5, 5, 8, 3, 2>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((blind_rotate16_kernel<2, 5, 8, 8>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
     }
 #else
@@ -721,6 +739,10 @@ int fheaes_create(const fheaes_params *params, int device, fheaes_ctx **out)
     };
     if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->cu_count = (uint32_t)cus;
+    }
     c->stream = c->own_stream;
     // twiddle tables
     const HostTwiddles &t = twiddles();

@@ -47,15 +47,15 @@ __device__ __forceinline__ int br16_opaque_tid()
     return t;
 }
 
-template <int K1, int LEVELS, int BASE_LOG, int R>
-__global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const ExtProdArgs A)
-{
-    static_assert(R * K1 <= EP_GROUPS, "too many polynomials for 16 lane groups");
-    // twiddle tables first: their addresses then fit the 16-bit offset field of the LDS instructions
 #ifndef BR16_PAD_DOUBLES
 #define BR16_PAD_DOUBLES 0     /* developer ablation: extra LDS so that only one workgroup fits a CU */
 #endif
-    __shared__ __attribute__((aligned(16))) double lds_all[EP_LDS_DOUBLES + BR16_PAD_DOUBLES];
+// One unit of work = R ciphertexts starting at `inst0`, one workgroup (the body of the kernel below).
+template <int K1, int LEVELS, int BASE_LOG, int R>
+__device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double *lds_all, const uint64_t inst0)
+{
+    static_assert(R * K1 <= EP_GROUPS, "too many polynomials for 16 lane groups");
+    // twiddle tables first: their addresses then fit the 16-bit offset field of the LDS instructions
     double2 *psi = reinterpret_cast<double2 *>(lds_all);
     double2 *tw = psi + FHE_H;
     double *lds = lds_all + 2 * 2 * FHE_H;                        // the 16 group tiles
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
     psi[tid] = A.psi[tid];
     tw[tid] = A.tw[tid];
 
-    uint64_t inst = (uint64_t)blockIdx.x * R + r_own;
+    uint64_t inst = inst0 + r_own;
     const bool valid = inst < A.count;
     if (!valid) inst = A.count - 1;
     const uint64_t *lwe = A.lwe_in + inst * (uint64_t)(A.iters + 1);
@@ -391,4 +391,21 @@ __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const Ext
             o[big] = lo[0] + A.post_add;
         }
     }
+}
+
+// The launch: workgroups 0 .. units_main-1 carry R ciphertexts each, the rest R2 (R2 = 0: none).  With more units than the chip
+// has slots (two per CU) the launcher picks both counts so that the total is a whole number of generations and covers the batch
+// exactly: 16,384 bits = 5,120 x 3 + 512 x 2 = 11 full generations, instead of 5,462 x 3 whose eleventh generation leaves a third of
+// the CUs idle for the length of a full one.  Workgroups are dispatched in index order, so the smaller units form the last generation.
+template <int K1, int LEVELS, int BASE_LOG, int R, int R2 = 0>
+__global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const ExtProdArgs A)
+{
+    __shared__ __attribute__((aligned(16))) double lds_all[EP_LDS_DOUBLES + BR16_PAD_DOUBLES];
+    if constexpr (R2 > 0) {
+        if (blockIdx.x >= A.units_main) {       // scalar branch
+            blind_rotate16_unit<K1, LEVELS, BASE_LOG, R2>(A, lds_all, (uint64_t)A.units_main * R + (uint64_t)(blockIdx.x - A.units_main) * R2);
+            return;
+        }
+    }
+    blind_rotate16_unit<K1, LEVELS, BASE_LOG, R>(A, lds_all, (uint64_t)blockIdx.x * R);
 }

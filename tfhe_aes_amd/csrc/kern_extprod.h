@@ -58,7 +58,8 @@ struct ExtProdArgs {
     uint32_t ggsw_per_input;    // VP: GGSWs per input in `ggsw` (= input bits; `iters` of them, the low bits, drive the rotation)
     uint64_t lut_words;         // VP: words per (LUT, output bit) in `luts` (512, or 2^bits when a CMUX tree ran first)
     const uint64_t *glwe_in;    // VP: non-null: the accumulator starts from this GLWE [instance][K1][512] (root of the CMUX tree)
-    uint64_t *park;             // kern_blindrot32.h: accumulator parking space, 64 KB per workgroup
+    uint64_t *park;             // kern_blindrot16.h: accumulator parking space, 64 KB per workgroup
+    uint32_t units_main;        // kern_blindrot16.h: workgroups below this index carry R ciphertexts, the others R2
 #ifdef EP_STAMPS
     unsigned long long *stamps; // developer build: per-wave cycles per phase [grid][4 waves][EP_NPH]
 #endif
