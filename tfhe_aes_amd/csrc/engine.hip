@@ -465,7 +465,14 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
             // more units than slots (two workgroups per CU): a whole number of generations of 3- and 2-ciphertext units that
             // cover the batch exactly, the 2-ciphertext ones last (see blind_rotate16_kernel)
             const uint64_t slots = 2ull * c->cu_count;
-            if (grid16 > slots) {
+#ifndef PBS_SMALL_R2
+#define PBS_SMALL_R2 1
+#endif
+            if (PBS_SMALL_R2 && (m + 1) / 2 <= c->cu_count) {
+                // at most one two-ciphertext unit per CU: shorter units than three-ciphertext ones, still one per CU
+                a.units_main = 0;
+                grid16 = (unsigned)((m + 1) / 2);
+            } else if (grid16 > slots) {
                 const uint64_t nu = slots * ((m + 3 * slots - 1) / (3 * slots));
                 if (2 * nu <= m) {
                     const uint64_t n2 = 3 * nu - m;

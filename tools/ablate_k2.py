@@ -28,7 +28,7 @@ VARIANTS = {
     "e14_stamps": ["-DBR16_EARLY=14", "-DEP_STAMPS"], "e15_stamps": ["-DBR16_EARLY=15", "-DEP_STAMPS"],
     "e15_one_wg_stamps": ["-DBR16_EARLY=15", "-DEP_STAMPS", "-DBR16_PAD_DOUBLES=2048"], "e15_one_wg": ["-DBR16_EARLY=15", "-DBR16_PAD_DOUBLES=2048"],
     "lat512": ["-DLATENCY_BATCH_BITS=512ull"], "lat768": ["-DLATENCY_BATCH_BITS=768ull"], "lat1024": ["-DLATENCY_BATCH_BITS=1024ull"],
-    "nobal": ["-DPBS_BALANCE=0"],
+    "nobal": ["-DPBS_BALANCE=0"], "nor2": ["-DPBS_SMALL_R2=0"],
     "aux1": ["-DEP_KEY_AUX=1"], "aux2": ["-DEP_KEY_AUX=2"], "aux16": ["-DEP_KEY_AUX=16"], "aux17": ["-DEP_KEY_AUX=17"],
     "aux18": ["-DEP_KEY_AUX=18"], "aux3": ["-DEP_KEY_AUX=3"], "aux19": ["-DEP_KEY_AUX=19"],
     "parknt": ["-DBR16_PARK_NT=1"], "parknt_aux2": ["-DBR16_PARK_NT=1", "-DEP_KEY_AUX=2"],
