@@ -159,6 +159,12 @@ int fheaes_profile_read(fheaes_ctx *ctx, int stage, double *total_ms, uint64_t *
 int fheaes_get_twiddles(double *psi_out);
 /* Fourier image of GGSW `i` of the uploaded BSK: out [pbs_level][k+1][k+1][256][2] */
 int fheaes_read_bsk_fourier(fheaes_ctx *ctx, uint32_t i, double *out);
+/* How a blind-rotation launch of `m` bits is cut into workgroups on a device with `cu_count` compute units at GLWE dimension k
+ * (host logic only, no GPU needed): `form` 0 = latency form (one ciphertext per workgroup), 1 = throughput form; `units_main`
+ * workgroups of `r_main` ciphertexts followed by `units_tail` of `r_tail`.  With more workgroups than the device has slots (two per
+ * CU) the counts make the launch a whole number of generations that covers the batch exactly. */
+int fheaes_k2_launch_plan(uint64_t m, uint32_t cu_count, uint32_t k, int *form, uint64_t *units_main, uint32_t *r_main,
+                          uint64_t *units_tail, uint32_t *r_tail);
 const char *fheaes_version(void);
 
 #ifdef __cplusplus

@@ -65,3 +65,34 @@ def test_param_struct_layout_matches_header():
     assert (c.lwe_dimension, c.glwe_dimension, c.polynomial_size) == (669, 4, 512)
     assert (c.pbs_base_log, c.pbs_level, c.ks_base_log, c.ks_level) == (8, 5, 2, 6)
     assert (c.pfks_base_log, c.pfks_level, c.cbs_base_log, c.cbs_level) == (12, 3, 15, 1)
+
+
+def test_k2_launch_plan_covers_the_batch_in_whole_generations():
+    """host logic of engine.hip::launch_cbs_pbs (no GPU): how a blind-rotation batch is cut into workgroups.  Latency form up to 256
+    bits; one two-ciphertext unit per CU up to 2 x CUs bits; one launch of three-ciphertext units while they fit the slots (two per
+    CU); beyond that three- and two-ciphertext units that cover the batch EXACTLY in a whole number of generations"""
+    import ctypes as C
+
+    lib = _native.load_library()
+    def plan(m, cus=256, k=4):
+        form, um, ut = C.c_int(), C.c_uint64(), C.c_uint64()
+        rm, rt = C.c_uint32(), C.c_uint32()
+        assert lib.fheaes_k2_launch_plan(m, cus, k, C.byref(form), C.byref(um), C.byref(rm), C.byref(ut), C.byref(rt)) == 0
+        return form.value, um.value, rm.value, ut.value, rt.value
+
+    assert plan(1) == (0, 1, 1, 0, 0) and plan(256)[:3] == (0, 256, 1)
+    assert plan(257) == (1, 0, 3, 129, 2) and plan(512) == (1, 0, 3, 256, 2)          # one 2-ciphertext unit per CU
+    assert plan(513)[:4] == (1, 171, 3, 0) and plan(1536)[:4] == (1, 512, 3, 0)        # fits the 512 slots
+    assert plan(16384) == (1, 5120, 3, 512, 2)                                         # BASELINE configs[2]: 11 generations
+    assert plan(4096) == (1, 1024, 3, 512, 2)                                          # a 32-block decrypt shard: 3 generations
+    assert plan(2100) == (1, 52, 3, 972, 2) and plan(32768) == (1, 10240, 3, 1024, 2)
+    assert plan(1600)[:4] == (1, 534, 3, 0)                                            # 2 generations of 2s and 3s cannot reach down to 1,600
+    for m in list(range(257, 6000, 7)) + [16383, 16385, 30000, 32768]:
+        form, um, rm, ut, rt = plan(m)
+        assert form == 1 and um * rm + ut * rt >= m
+        if ut and um + ut > 512:
+            assert um * 3 + ut * 2 == m and (um + ut) % 512 == 0
+    assert plan(530, k=1)[:4] == (1, 67, 8, 0)                                         # toy parameter set: 8 ciphertexts per unit, no tail
+    for bad in ((0, 256), (16, 0)):
+        f = C.c_int(); a = C.c_uint64(); b = C.c_uint32(); c = C.c_uint64(); d = C.c_uint32()
+        assert lib.fheaes_k2_launch_plan(bad[0], bad[1], 4, C.byref(f), C.byref(a), C.byref(b), C.byref(c), C.byref(d)) != 0

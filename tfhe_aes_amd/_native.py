@@ -54,6 +54,8 @@ SIGNATURES = {
     "fheaes_profile_read": (_c.c_int, [_ctx, _c.c_int, _dp, _u64p, _u64p]),
     "fheaes_get_twiddles": (_c.c_int, [_dp]),
     "fheaes_read_bsk_fourier": (_c.c_int, [_ctx, _c.c_uint32, _dp]),
+    "fheaes_k2_launch_plan": (_c.c_int, [_c.c_uint64, _c.c_uint32, _c.c_uint32, _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint32),
+                                       _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint32)]),
     "fheaes_version": (_c.c_char_p, []),
 }
 

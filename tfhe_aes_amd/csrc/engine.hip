@@ -346,6 +346,44 @@ struct StampReport {
 };
 #endif
 
+// ---- how a blind-rotation batch is cut into workgroups (fheaes_k2_launch_plan) -------------------------------------------------
+#ifndef LATENCY_BATCH_BITS
+#define LATENCY_BATCH_BITS 256ull      /* at most one 512-thread workgroup per CU */
+#endif
+#ifndef PBS_BALANCE
+#define PBS_BALANCE 1
+#endif
+#ifndef PBS_SMALL_R2
+#define PBS_SMALL_R2 1
+#endif
+struct K2Plan { int form; uint64_t units_main; uint32_t r_main; uint64_t units_tail; uint32_t r_tail; };
+K2Plan k2_plan(uint64_t m, uint32_t cu_count, uint32_t k1)
+{
+    K2Plan pl{};
+    if (m <= LATENCY_BATCH_BITS) { pl.form = 0; pl.units_main = m; pl.r_main = 1; return pl; }
+    pl.form = 1;
+    pl.r_main = k1 == 5 ? 3 : 8;
+    pl.units_main = (m + pl.r_main - 1) / pl.r_main;
+    if (PBS_BALANCE && k1 == 5) {
+        const uint64_t slots = 2ull * cu_count;
+        pl.r_tail = 2;
+        if (PBS_SMALL_R2 && (m + 1) / 2 <= cu_count) {
+            // at most one two-ciphertext unit per CU: shorter units than three-ciphertext ones, still one per CU
+            pl.units_main = 0;
+            pl.units_tail = (m + 1) / 2;
+        } else if (pl.units_main > slots) {
+            // more units than slots (two workgroups per CU): a whole number of generations of 3- and 2-ciphertext units that
+            // cover the batch exactly, the 2-ciphertext ones last (see blind_rotate16_kernel)
+            const uint64_t nu = slots * ((m + 3 * slots - 1) / (3 * slots));
+            if (2 * nu <= m) {
+                pl.units_tail = 3 * nu - m;
+                pl.units_main = nu - pl.units_tail;
+            }
+        }
+    }
+    return pl;
+}
+
 // ---- kernel launchers ------------------------------------------------------------------------
 int launch_keyswitch(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *out)
 {
@@ -418,9 +456,6 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
     a.out = out; a.count = m; a.iters = c->n; a.lwe_in = lwe_small;
     const uint64_t half_delta = 1ull << (64 - c->p.cbs_base_log * level - 1);
     a.tv_const = (uint64_t)0 - half_delta; a.body_shift = 1ull << 62; a.post_add = half_delta;
-#ifndef LATENCY_BATCH_BITS
-#define LATENCY_BATCH_BITS 256ull      /* at most one 512-thread workgroup per CU */
-#endif
     if (m <= LATENCY_BATCH_BITS) {
         // latency regime: one ciphertext per 512-thread workgroup, all levels transformed at once (kern_blindrot_latency.h)
 #ifdef EP_STAMPS
@@ -455,32 +490,9 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
 #if PBS_FORM16
     } else {
         // throughput form (kern_blindrot16.h): accumulator parked in HBM between uses, key rows prefetched across the transform
-        const unsigned R16 = c->k1 == 5 ? 3 : 8;
-        unsigned grid16 = (unsigned)((m + R16 - 1) / R16);
-        a.units_main = grid16;
-#ifndef PBS_BALANCE
-#define PBS_BALANCE 1
-#endif
-        if (PBS_BALANCE && c->k1 == 5) {
-            // more units than slots (two workgroups per CU): a whole number of generations of 3- and 2-ciphertext units that
-            // cover the batch exactly, the 2-ciphertext ones last (see blind_rotate16_kernel)
-            const uint64_t slots = 2ull * c->cu_count;
-#ifndef PBS_SMALL_R2
-#define PBS_SMALL_R2 1
-#endif
-            if (PBS_SMALL_R2 && (m + 1) / 2 <= c->cu_count) {
-                // at most one two-ciphertext unit per CU: shorter units than three-ciphertext ones, still one per CU
-                a.units_main = 0;
-                grid16 = (unsigned)((m + 1) / 2);
-            } else if (grid16 > slots) {
-                const uint64_t nu = slots * ((m + 3 * slots - 1) / (3 * slots));
-                if (2 * nu <= m) {
-                    const uint64_t n2 = 3 * nu - m;
-                    a.units_main = (uint32_t)(nu - n2);
-                    grid16 = (unsigned)nu;
-                }
-            }
-        }
+        const K2Plan pl = k2_plan(m, c->cu_count, c->k1);
+        const unsigned grid16 = (unsigned)(pl.units_main + pl.units_tail);
+        a.units_main = (uint32_t)pl.units_main;
         TRY(ensure(c, c->ws_park, (size_t)grid16 * BR16_PARK_WORDS_PER_WG * 8));
         a.park = (uint64_t *)c->ws_park.p;
 #ifdef EP_STAMPS
@@ -708,6 +720,14 @@ int supported(const fheaes_params *p, std::string &why)
 // ---------------------------------------------------------------------------------------------
 extern "C" {
 
+int fheaes_k2_launch_plan(uint64_t m, uint32_t cu_count, uint32_t k, int *form, uint64_t *units_main, uint32_t *r_main,
+                          uint64_t *units_tail, uint32_t *r_tail)
+{
+    if (!form || !units_main || !r_main || !units_tail || !r_tail || cu_count == 0 || m == 0) return FHEAES_ERR_INVALID;
+    const K2Plan pl = k2_plan(m, cu_count, k + 1);
+    *form = pl.form; *units_main = pl.units_main; *r_main = pl.r_main; *units_tail = pl.units_tail; *r_tail = pl.r_tail;
+    return FHEAES_OK;
+}
 const char *fheaes_version(void) { return FHEAES_VERSION_STR; }
 
 const char *fheaes_last_error(const fheaes_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
