@@ -39,21 +39,6 @@ def test_decomposition(b, level):
         assert recomposed == closest
 
 
-@pytest.mark.parametrize("b", [8, 2, 12])
-def test_state_advance_identity(b):
-    """fft_dev.h decompose_advance (the latency kernel's peel without digits): the state update of the balanced decomposition,
-    state' = (state >> b) + carry with carry = bit (b-1) of (((d-1) | (state >> b)) & d), equals (state + (B/2 - 1) + bit(2b-1)(state)) >> b
-    for every state below 2^32 - B/2: exhaustively over the low 2b bits (all that the carry depends on), and on random states"""
-    half = 1 << (b - 1)
-    rng = np.random.default_rng(b)
-    states = list(range(1 << min(2 * b, 18))) + [int(v) for v in rng.integers(0, (1 << 32) - half, 20000, dtype=np.uint64)] + [(1 << 32) - half - 1]
-    for s in states:
-        d = s & ((1 << b) - 1)
-        st = s >> b
-        carry = ((((d - 1) & M64) | st) & d) >> (b - 1)
-        assert st + carry == (s + (half - 1) + ((s >> (2 * b - 1)) & 1)) >> b
-
-
 def test_mod_switch():
     assert orc.mod_switch(0) == 0
     assert orc.mod_switch(1 << 54) == 1

@@ -289,17 +289,6 @@ __device__ __forceinline__ int decompose_first(uint64_t x, uint32_t &state)
     return (int)d - (int)(carry << BASE_LOG);
 }
 
-// The state update of decompose_next alone (no digit), in three instructions:
-//   carry = [d > B/2] or [d == B/2 and bit (BASE_LOG - 1) of the remaining state is set]   (d = state mod B)
-//         = (d + (B/2 - 1) + bit(2*BASE_LOG - 1)(state)) >> BASE_LOG,
-// hence state' = (state + (B/2 - 1) + bit(2*BASE_LOG - 1)(state)) >> BASE_LOG.  Requires state < 2^32 - B/2 (true from the second
-// peel on: the state then has at most 32 - BASE_LOG + 1 bits); tests/test_oracle_primitives.py checks it against decompose_next.
-template <int BASE_LOG>
-__device__ __forceinline__ uint32_t decompose_advance(uint32_t state)
-{
-    return (state + ((1u << (BASE_LOG - 1)) - 1u) + ((state >> (2 * BASE_LOG - 1)) & 1u)) >> BASE_LOG;
-}
-
 template <int BASE_LOG>
 __device__ __forceinline__ int decompose_next(uint32_t &state)
 {
