@@ -117,3 +117,32 @@ def test_1024_ctr_blocks_on_one_gpu(opt, opt_server):
     for i in range(n):
         want = aes_clear.aes128_encrypt_block(key, (IV + i) & ((1 << 128) - 1))
         assert [int(x) for x in got[i]] == [(want >> (8 * (15 - b))) & 0xFF for b in range(16)], "block %d" % i
+
+
+def test_k2_launch_forms_agree_at_full_size(opt):
+    """BASELINE configs[2] launches 16,384 bits of blind rotation at a time: 5,120 three-ciphertext + 512 two-ciphertext workgroups in
+    one kernel (fheaes_k2_launch_plan).  The oracle would need minutes for that batch; the size-independent property is that
+    the cut of a batch into launches and workgroups does not change a single word: the same rows in 1,024-bit launches
+    (342 three-ciphertext workgroups, no tail), in a 4,096-bit launch (1,024 + 512), and -- for the first 256 rows -- in the latency
+    form (one ciphertext per 512-thread workgroup) give identical outputs."""
+    import torch
+
+    p, E = opt.params, opt.engine()
+    rng = np.random.default_rng(16384)
+    m = 16384
+    small = torch.from_numpy(rng.integers(0, 1 << 64, (m, p.n + 1), dtype=np.uint64).view(np.int64)).cuda()
+    full = torch.empty((m, p.big1), dtype=torch.int64, device="cuda")
+    E.cbs_pbs_batch(small, full, m)
+    E.synchronize()
+    part = torch.empty_like(full)
+    for lo in range(0, m, 1024):
+        E.cbs_pbs_batch(small[lo:lo + 1024], part[lo:lo + 1024], 1024)
+    E.synchronize()
+    assert torch.equal(full, part)
+    mid = torch.empty((4096, p.big1), dtype=torch.int64, device="cuda")
+    E.cbs_pbs_batch(small[4096:8192], mid, 4096)
+    lat = torch.empty((256, p.big1), dtype=torch.int64, device="cuda")
+    E.cbs_pbs_batch(small[:256], lat, 256)
+    E.synchronize()
+    assert torch.equal(full[4096:8192], mid) and torch.equal(full[:256], lat)
+    assert sha(full.cpu().numpy()) != sha(np.zeros_like(full.cpu().numpy()))
