@@ -34,12 +34,12 @@
  *
  * CANONICAL ARITHMETIC (the HIP engine must reproduce these bit for bit):
  *   - all torus arithmetic is uint64 wrapping;
- *   - polynomial products in Z[X]/(X^512+1) use a 256-point complex f64 FFT
- *     (fold + twist), decomposed 16 x 16: DFT16 over rows (radix-2 DIF, natural
- *     order out), twiddle by w256^(k1*b), transpose, DFT16 over rows;
+ *   - polynomial products in Z[X]/(X^512+1) use a 256-point complex f64 FFT of the folded
+ *     polynomial, decomposed 16 x 16 with the negacyclic twist merged into the first pass
+ *     (see "256-point transform ... canonical form, v2" below): offset-1/4 DFT16 (radix-2 DIT,
+ *     fused butterflies), twiddle by psi^(b(4 k1+1)), transpose, plain DFT16 (radix-2 DIT);
  *   - complex multiply  cmul(x,w):  re = fma(xr,wr,-(xi*wi)); im = fma(xr,wi, xi*wr)
- *     conjugate multiply cmulc(x,w): re = fma(xr,wr,  xi*wi ); im = fma(xi,wr,-(xr*wi))
- *     multiplication by 1 / +-i is a copy / swap-negate;
+ *     conjugate multiply cmulc(x,w): re = fma(xr,wr,  xi*wi ); im = fma(xi,wr,-(xr*wi));
  *   - pointwise multiply-accumulate is one sequential chain per (output poly, point),
  *     levels from the LEAST significant (l = L-1) to the most significant (l = 0), rows r
  *     ascending inside a level:  re = fma(dr,br,re); re = fma(-di,bi,re);
@@ -83,6 +83,7 @@ typedef struct {
 static double PSI_RE[NPOLY], PSI_IM[NPOLY];   /* psi^j = exp(i pi j / 512), j < 512 */
 static double W256_RE[HALF], W256_IM[HALF];   /* exp(2 pi i m / 256) = psi^(4m)      */
 static int g_init_done = 0;
+static void init_tw_table(void);
 
 static void init_twiddles(void)
 {
@@ -112,6 +113,7 @@ static void init_twiddles(void)
         if (e < 512) { W256_RE[m] = PSI_RE[e]; W256_IM[m] = PSI_IM[e]; }
         else { W256_RE[m] = -PSI_RE[e - 512]; W256_IM[m] = -PSI_IM[e - 512]; }
     }
+    init_tw_table();
     g_init_done = 1;
 }
 
@@ -124,46 +126,64 @@ void orc_get_twiddles(double *psi_interleaved /* [512][2] */)
 }
 
 /* ------------------------------------------------------------------------- */
-/* 256-point FFT, 16 x 16                                                     */
+/* 256-point transform of the folded polynomial, 16 x 16 (canonical form, v2)  */
 /* ------------------------------------------------------------------------- */
+/* z_j = p_j + i p_{j+256} (j = 16a + b).  The negacyclic twist psi^j is NOT a separate pass:
+ *   X_k = sum_j z_j e^{2 pi i j (k + 1/4) / 256},   k = k1 + 16 k2
+ *       = sum_b e^{2 pi i b k2 / 16} . T[k1][b] . sum_a z_{16a+b} e^{2 pi i a (k1 + 1/4) / 16}
+ * with T[k1][b] = e^{2 pi i b (k1 + 1/4) / 256} = psi^(b (4 k1 + 1)):
+ *   pass 1  DFT16 over a with frequency offset 1/4 (radix-2 DIT; stage n uses e^{2 pi i (k + 1/4)/n}: constants),
+ *   then    multiply by T[k1][b] (cmul, all 256 entries),
+ *   pass 2  plain DFT16 over b (radix-2 DIT; twiddles 1 and +-i are additions).
+ * Inverse: plain conjugate DFT16 over k2, multiply by conj T[k1][b] (b >= 1), plain conjugate DFT16 over k1,
+ * multiply by conj psi^(16a) (a >= 1).
+ * DIT butterfly with a non-trivial twiddle w = (c, s), 6 fused operations:
+ *   ur = fma(-s, qi, fma(c, qr, pr));  ui = fma(s, qr, fma(c, qi, pi));      u = p + w q
+ *   vr = fma(2, pr, -ur);              vi = fma(2, pi, -ui);                 v = p - w q = 2p - u
+ * (conjugate twiddle: s -> -s).  The HIP kernels (csrc/fft_dev.h) evaluate the same expression tree. */
 static const int BITREV4[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
+static double TW_RE[16][16], TW_IM[16][16];      /* T[k1][b] = psi^(b (4 k1 + 1)) */
 
-/* DFT of length 16 over the FIRST index of x[16][16] for each column, in place,
- * natural-order output.  inverse=0: kernel e^{+2 pi i a k/16}; inverse=1: conjugate. */
-static void dft16_rows(double xr[16][16], double xi[16][16], int inverse)
+static void init_tw_table(void)
 {
-    for (int half = 8; half >= 1; half >>= 1) {
-        int step = 8 / half;
-        for (int blk = 0; blk < 16; blk += 2 * half) {
-            for (int a = 0; a < half; ++a) {
-                int m = a * step;                 /* twiddle w16^m, m in 0..7 */
-                int p = blk + a, q = p + half;
-                double wr = W256_RE[16 * m], wi = W256_IM[16 * m];
-                for (int c = 0; c < 16; ++c) {
-                    double ur = xr[p][c] + xr[q][c], ui = xi[p][c] + xi[q][c];
-                    double dr = xr[p][c] - xr[q][c], di = xi[p][c] - xi[q][c];
-                    xr[p][c] = ur; xi[p][c] = ui;
-                    if (m == 0) { xr[q][c] = dr; xi[q][c] = di; }
-                    else if (m == 4) {
-                        if (!inverse) { xr[q][c] = -di; xi[q][c] = dr; }   /* * (+i) */
-                        else          { xr[q][c] = di;  xi[q][c] = -dr; }  /* * (-i) */
-                    } else if (!inverse) {
-                        xr[q][c] = fma(dr, wr, -(di * wi));
-                        xi[q][c] = fma(dr, wi, di * wr);
-                    } else {
-                        xr[q][c] = fma(dr, wr, di * wi);
-                        xi[q][c] = fma(di, wr, -(dr * wi));
-                    }
+    for (int k1 = 0; k1 < 16; ++k1) for (int b = 0; b < 16; ++b) {
+        int e = (b * (4 * k1 + 1)) & 1023;
+        if (e < 512) { TW_RE[k1][b] = PSI_RE[e]; TW_IM[k1][b] = PSI_IM[e]; }
+        else { TW_RE[k1][b] = -PSI_RE[e - 512]; TW_IM[k1][b] = -PSI_IM[e - 512]; }
+    }
+}
+
+/* DFT of length 16 over the FIRST index of x[16][16] for each column, in place, natural order in and out.
+ * inverse=0: kernel e^{+2 pi i a (k + phi)/16}, phi = offset ? 1/4 : 0; inverse=1: conjugate kernel (offset must be 0). */
+static void dft16_rows(double xr[16][16], double xi[16][16], int inverse, int offset)
+{
+    double tr[16][16], ti[16][16];
+    for (int p = 0; p < 16; ++p) { memcpy(tr[p], xr[BITREV4[p]], sizeof tr[p]); memcpy(ti[p], xi[BITREV4[p]], sizeof ti[p]); }
+    for (int n = 2; n <= 16; n <<= 1) {
+        int half = n / 2;
+        for (int blk = 0; blk < 16; blk += n) for (int k = 0; k < half; ++k) {
+            int e = offset ? (64 * k + 16) / n : 64 * k / n;       /* twiddle = psi^(16 e), e in 0..31 */
+            double c = PSI_RE[16 * e], s = PSI_IM[16 * e];
+            if (inverse) s = -s;
+            int P = blk + k, Q = P + half;
+            for (int col = 0; col < 16; ++col) {
+                double pr = tr[P][col], pi = ti[P][col], qr = tr[Q][col], qi = ti[Q][col];
+                double ur, ui, vr, vi;
+                if (e == 0) { ur = pr + qr; ui = pi + qi; vr = pr - qr; vi = pi - qi; }
+                else if (e == 16) {                                 /* w = +i (forward) / -i (inverse) */
+                    if (!inverse) { ur = pr - qi; ui = pi + qr; vr = pr + qi; vi = pi - qr; }
+                    else          { ur = pr + qi; ui = pi - qr; vr = pr - qi; vi = pi + qr; }
+                } else {
+                    ur = fma(-s, qi, fma(c, qr, pr));
+                    ui = fma(s, qr, fma(c, qi, pi));
+                    vr = fma(2.0, pr, -ur);
+                    vi = fma(2.0, pi, -ui);
                 }
+                tr[P][col] = ur; ti[P][col] = ui; tr[Q][col] = vr; ti[Q][col] = vi;
             }
         }
     }
-    double tr[16][16], ti[16][16];
-    memcpy(tr, xr, sizeof tr); memcpy(ti, xi, sizeof ti);
-    for (int p = 0; p < 16; ++p) {
-        memcpy(xr[BITREV4[p]], tr[p], sizeof tr[p]);
-        memcpy(xi[BITREV4[p]], ti[p], sizeof ti[p]);
-    }
+    memcpy(xr, tr, sizeof tr); memcpy(xi, ti, sizeof ti);
 }
 
 static void transpose16(double x[16][16])
@@ -171,32 +191,38 @@ static void transpose16(double x[16][16])
     for (int a = 0; a < 16; ++a) for (int b = a + 1; b < 16; ++b) { double t = x[a][b]; x[a][b] = x[b][a]; x[b][a] = t; }
 }
 
-/* in: z[16a+b]; out: X[k] natural order, X_k = sum_j z_j e^{+2 pi i jk/256} */
+/* in: z[16a+b] (untwisted fold); out: X[k] natural order, X_k = sum_j z_j e^{+2 pi i j(k+1/4)/256} */
 static void fft256_fwd(double zr[16][16], double zi[16][16])
 {
-    dft16_rows(zr, zi, 0);                                   /* [k1][b] */
-    for (int k1 = 1; k1 < 16; ++k1) for (int b = 1; b < 16; ++b) {
-        double wr = W256_RE[k1 * b], wi = W256_IM[k1 * b];
+    dft16_rows(zr, zi, 0, 1);                                /* [k1][b] */
+    for (int k1 = 0; k1 < 16; ++k1) for (int b = 0; b < 16; ++b) {
+        double wr = TW_RE[k1][b], wi = TW_IM[k1][b];
         double xr = zr[k1][b], xi = zi[k1][b];
         zr[k1][b] = fma(xr, wr, -(xi * wi));
         zi[k1][b] = fma(xr, wi, xi * wr);
     }
     transpose16(zr); transpose16(zi);                        /* [b][k1] */
-    dft16_rows(zr, zi, 0);                                   /* [k2][k1] = X[k1+16k2] */
+    dft16_rows(zr, zi, 0, 0);                                /* [k2][k1] = X[k1+16k2] */
 }
 
-/* in: X[k] natural; out: z[16a+b] = sum_k X_k e^{-2 pi i jk/256} (unscaled) */
+/* in: X[k] natural; out: z[16a+b] = sum_k X_k e^{-2 pi i j(k+1/4)/256} (unscaled; the untwist is included) */
 static void fft256_inv(double zr[16][16], double zi[16][16])
 {
-    dft16_rows(zr, zi, 1);                                   /* [b][k1] */
-    for (int b = 1; b < 16; ++b) for (int k1 = 1; k1 < 16; ++k1) {
-        double wr = W256_RE[k1 * b], wi = W256_IM[k1 * b];
+    dft16_rows(zr, zi, 1, 0);                                /* [b][k1] */
+    for (int b = 1; b < 16; ++b) for (int k1 = 0; k1 < 16; ++k1) {
+        double wr = TW_RE[k1][b], wi = TW_IM[k1][b];
         double xr = zr[b][k1], xi = zi[b][k1];
         zr[b][k1] = fma(xr, wr, xi * wi);
         zi[b][k1] = fma(xi, wr, -(xr * wi));
     }
     transpose16(zr); transpose16(zi);                        /* [k1][b] */
-    dft16_rows(zr, zi, 1);                                   /* [a][b] */
+    dft16_rows(zr, zi, 1, 0);                                /* [a][b] */
+    for (int a = 1; a < 16; ++a) for (int b = 0; b < 16; ++b) {
+        double wr = PSI_RE[16 * a], wi = PSI_IM[16 * a];
+        double xr = zr[a][b], xi = zi[a][b];
+        zr[a][b] = fma(xr, wr, xi * wi);
+        zi[a][b] = fma(xi, wr, -(xr * wi));
+    }
 }
 
 /* forward negacyclic transform of a real polynomial given as doubles */
@@ -204,14 +230,7 @@ static void nega_fwd(const double *p /*[512]*/, double *fr /*[256]*/, double *fi
 {
     double zr[16][16], zi[16][16];
     double *r = &zr[0][0], *im = &zi[0][0];
-    for (int j = 0; j < HALF; ++j) {
-        double xr = p[j], xi = p[j + HALF];
-        if (j == 0) { r[j] = xr; im[j] = xi; }
-        else {
-            r[j] = fma(xr, PSI_RE[j], -(xi * PSI_IM[j]));
-            im[j] = fma(xr, PSI_IM[j], xi * PSI_RE[j]);
-        }
-    }
+    for (int j = 0; j < HALF; ++j) { r[j] = p[j]; im[j] = p[j + HALF]; }
     fft256_fwd(zr, zi);
     memcpy(fr, r, HALF * sizeof(double)); memcpy(fi, im, HALF * sizeof(double));
 }
@@ -233,14 +252,8 @@ static void nega_inv_add(const double *fr, const double *fi, uint64_t *acc)
     memcpy(r, fr, HALF * sizeof(double)); memcpy(im, fi, HALF * sizeof(double));
     fft256_inv(zr, zi);
     for (int j = 0; j < HALF; ++j) {
-        double xr = r[j], xi = im[j], ur, ui;
-        if (j == 0) { ur = xr; ui = xi; }
-        else {
-            ur = fma(xr, PSI_RE[j], xi * PSI_IM[j]);
-            ui = fma(xi, PSI_RE[j], -(xr * PSI_IM[j]));
-        }
-        acc[j] += torus_from_double(ur);
-        acc[j + HALF] += torus_from_double(ui);
+        acc[j] += torus_from_double(r[j]);
+        acc[j + HALF] += torus_from_double(im[j]);
     }
 }
 

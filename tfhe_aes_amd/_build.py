@@ -45,9 +45,12 @@ def hipcc_path() -> str:
 
 def engine_flags():
     # -ffp-contract=off: the canonical arithmetic only fuses where the source says fma()
+    # -disable-machine-licm: the transforms' ~50 lane-independent twiddle constants are 64-bit literals moved into SGPR pairs;
+    #   hoisted out of the 669-iteration loop they would all be live at once (12 SGPRs spilled to a VGPR, 20 B/lane of scratch in
+    #   the blind rotation); left where they are used they cost a scalar move each, on the otherwise idle scalar unit
     return [
         "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-        "-ffp-contract=off", "-fno-fast-math", "-Wall",
+        "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-disable-machine-licm", "-Wall",
         "-Wno-unused-function", "-I", str(ROOT / "include"), "-I", str(CSRC),
     ]
 

@@ -66,9 +66,10 @@ struct HostTwiddles {
         for (int j = 129; j <= 256; ++j) { psi_re[j] = psi_im[256 - j]; psi_im[j] = psi_re[256 - j]; }
         for (int j = 257; j < 512; ++j) { psi_re[j] = -psi_re[512 - j]; psi_im[j] = psi_im[512 - j]; }
     }
-    void w256(int m, double &re, double &im) const
+    // psi^e, e mod 1024
+    void pow(int e, double &re, double &im) const
     {
-        int e = 4 * m;
+        e &= 1023;
         if (e < 512) { re = psi_re[e]; im = psi_im[e]; }
         else { re = -psi_re[e - 512]; im = -psi_im[e - 512]; }
     }
@@ -203,8 +204,7 @@ struct fheaes_ctx {
     double2 *bskf = nullptr;
     bool have_keys = false;
     // tables
-    double2 *psi_d = nullptr, *tw_d = nullptr;
-    FftConsts fc{};
+    double2 *tw_d = nullptr;            // the transform's table T[17 k1 + b] = psi^(b (4 k1 + 1)) (fft_dev.h)
     uint64_t *lutset_d[LUTSET_COUNT] = {};
     int lutset_n[LUTSET_COUNT] = {};
     // workspace
@@ -439,7 +439,7 @@ int launch_forward_fourier(fheaes_ctx *c, const uint64_t *in, uint64_t polys, do
     StageScope sc(c, stage, polys);
     uint64_t wgs = (polys + EP_GROUPS - 1) / EP_GROUPS;
     if (wgs > 8192) wgs = 8192;
-    hipLaunchKernelGGL(forward_fourier_kernel, dim3((unsigned)wgs), dim3(EP_THREADS), 0, c->stream, in, out, polys, c->psi_d, c->tw_d, c->fc);
+    hipLaunchKernelGGL(forward_fourier_kernel, dim3((unsigned)wgs), dim3(EP_THREADS), 0, c->stream, in, out, polys, c->tw_d);
     HIP_TRY(c, hipGetLastError());
     return FHEAES_OK;
 }
@@ -452,7 +452,7 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         return c->fail(FHEAES_ERR_INVALID, "bootstrapping key larger than 2 GiB is not supported by the blind-rotation kernels");
     StageScope sc(c, FHEAES_STAGE_BLIND_ROTATE, m);
     ExtProdArgs a{};
-    a.ggsw = c->bskf; a.psi = c->psi_d; a.tw = c->tw_d; a.fc = c->fc;
+    a.ggsw = c->bskf; a.tw = c->tw_d;
     a.out = out; a.count = m; a.iters = c->n; a.lwe_in = lwe_small;
     const uint64_t half_delta = 1ull << (64 - c->p.cbs_base_log * level - 1);
     a.tv_const = (uint64_t)0 - half_delta; a.body_shift = 1ull << 62; a.post_add = half_delta;
@@ -493,8 +493,10 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         const K2Plan pl = k2_plan(m, c->cu_count, c->k1);
         const unsigned grid16 = (unsigned)(pl.units_main + pl.units_tail);
         a.units_main = (uint32_t)pl.units_main;
-        TRY(ensure(c, c->ws_park, (size_t)grid16 * BR16_PARK_WORDS_PER_WG * 8));
-        a.park = (uint64_t *)c->ws_park.p;
+        const size_t park_bytes = (size_t)grid16 * BR16_PARK_WORDS_PER_WG * 8;
+        if (park_bytes > 0x7FFFFFFFull) return c->fail(FHEAES_ERR_INVALID, "internal: parking slab of %zu bytes exceeds one raw buffer", park_bytes);
+        TRY(ensure(c, c->ws_park, park_bytes));
+        a.park = (uint64_t *)c->ws_park.p; a.park_bytes = park_bytes;
 #ifdef EP_STAMPS
         static const char *names16[EP_NPH] = {"stage+rotate+decomp_first", "decomp_next", "fwd head", "pre-level barrier", "fwd tail (transpose+dft16)",
                                               "digit stores+late loads", "exchange barrier", "MAC", "products exchange", "inverse fft", "convert+add", "loop head"};
@@ -562,7 +564,7 @@ int launch_vertical_packing(fheaes_ctx *c, const double2 *ggswf, uint64_t n_inpu
         uint64_t *buf[2] = {(uint64_t *)c->ws_tree.p, (uint64_t *)c->ws_tree.p + half_words};
         for (uint32_t t = 0; t < tree_bits; ++t) {
             CmuxArgs a{};
-            a.ggsw = ggswf; a.psi = c->psi_d; a.tw = c->tw_d; a.fc = c->fc;
+            a.ggsw = ggswf; a.tw = c->tw_d;
             a.luts = t == 0 ? luts : nullptr; a.in = t == 0 ? nullptr : buf[(t - 1) & 1]; a.out = buf[t & 1];
             a.bits = bits; a.bit = 9 + t; a.nodes_out = 1u << (tree_bits - 1 - t);
             a.inst_per_input = inst_per_input; a.lut_per_input = per_input ? 1 : 0; a.lut_words = W;
@@ -581,7 +583,7 @@ int launch_vertical_packing(fheaes_ctx *c, const double2 *ggswf, uint64_t n_inpu
         glwe_root = buf[(tree_bits - 1) & 1];
     }
     ExtProdArgs a{};
-    a.ggsw = ggswf; a.psi = c->psi_d; a.tw = c->tw_d; a.fc = c->fc;
+    a.ggsw = ggswf; a.tw = c->tw_d;
     a.out = out; a.count = n_inputs * n_luts * bits; a.iters = bits < 9 ? bits : 9; a.ggsw_per_input = bits;
     a.luts = luts; a.lut_words = W; a.glwe_in = glwe_root;
     a.n_luts = n_luts; a.lut_per_input = per_input ? 1 : 0; a.inst_per_input = inst_per_input;
@@ -773,14 +775,18 @@ int fheaes_create(const fheaes_params *params, int device, fheaes_ctx **out)
     c->stream = c->own_stream;
     // twiddle tables
     const HostTwiddles &t = twiddles();
-    std::vector<double2> psi(FHE_H), tw(FHE_H);
-    for (int j = 0; j < FHE_H; ++j) { psi[j].x = t.psi_re[j]; psi[j].y = t.psi_im[j]; }
-    for (int k1 = 0; k1 < 16; ++k1) for (int b = 0; b < 16; ++b) { double re, im; t.w256((k1 * b) & 255, re, im); tw[16 * k1 + b].x = re; tw[16 * k1 + b].y = im; }
-    c->fc.c1 = t.psi_re[64]; c->fc.s1 = t.psi_im[64]; c->fc.h = t.psi_re[128];
-    if ((e = hipMalloc((void **)&c->psi_d, FHE_H * sizeof(double2))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMalloc((void **)&c->tw_d, FHE_H * sizeof(double2))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMemcpy(c->psi_d, psi.data(), FHE_H * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
-    if ((e = hipMemcpy(c->tw_d, tw.data(), FHE_H * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+    std::vector<double2> tw(FHE_TW_ENTRIES);
+    for (auto &w : tw) { w.x = 0.0; w.y = 0.0; }
+    for (int k1 = 0; k1 < 16; ++k1) for (int b = 0; b < 16; ++b) { double re, im; t.pow(b * (4 * k1 + 1), re, im); tw[FHE_TW_STRIDE * k1 + b].x = re; tw[FHE_TW_STRIDE * k1 + b].y = im; }
+    // the kernels' compile-time constants (fft_consts.h, generated from this table) must BE this table
+    for (int m = 0; m < 32; ++m)
+        if (FHE_PSI16_RE[m] != t.psi_re[16 * m] || FHE_PSI16_IM[m] != t.psi_im[16 * m]) {
+            g_create_error = "fft_consts.h does not match the twiddle table (regenerate it: tools/gen_fft_consts.py)";
+            fheaes_destroy(c);
+            return FHEAES_ERR_INVALID;
+        }
+    if ((e = hipMalloc((void **)&c->tw_d, FHE_TW_ENTRIES * sizeof(double2))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemcpy(c->tw_d, tw.data(), FHE_TW_ENTRIES * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
     // AES LUT sets, built once (the reference rebuilds them on every call: sbox.rs:54-60, :85-94)
     for (int s = 0; s < LUTSET_COUNT; ++s) {
         std::vector<uint64_t> h;
@@ -799,7 +805,7 @@ void fheaes_destroy(fheaes_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &pe : c->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : c->free_events) (void)hipEventDestroy(ev);
-    void *ptrs[] = {c->ksk_frag, c->pfpksk_frag, c->bskf, c->psi_d, c->tw_d, c->ws_digits.p,
+    void *ptrs[] = {c->ksk_frag, c->pfpksk_frag, c->bskf, c->tw_d, c->ws_digits.p,
                     c->ws_small.p, c->ws_pbs.p, c->ws_ggsw.p, c->ws_ggswf.p, c->ws_vp.p, c->ws_tmp_a.p, c->ws_tmp_b.p, c->ws_luts.p, c->ws_misc.p,
                     c->ws_park.p, c->ws_tree.p};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -850,6 +856,11 @@ int fheaes_reserve(fheaes_ctx *c, uint64_t max_bits)
     TRY(ensure(c, c->ws_pbs, bits * c->big1 * 8));
     TRY(ensure(c, c->ws_ggsw, bits * ggsw_words * 8));
     TRY(ensure(c, c->ws_ggswf, bits * ggsw_words * 8));
+    {
+        // the blind rotation's parking slab for the largest launch this reservation covers (64 KB per workgroup)
+        const K2Plan pl = k2_plan(bits, c->cu_count, c->k1);
+        if (pl.form == 1) TRY(ensure(c, c->ws_park, (size_t)(pl.units_main + pl.units_tail) * BR16_PARK_WORDS_PER_WG * 8));
+    }
     return FHEAES_OK;
 }
 

@@ -5,25 +5,39 @@
 // points per lane, so the 256-point transform is two in-register DFT16 passes with ONE transpose
 // through LDS (a 16 x 17 padded tile per group: conflict-free ds_write_b128 / ds_read_b128).
 //
-// The arithmetic is the canonical one stated in oracle/fheaes_oracle.c (header) and DESIGN.md:
-//   fold+twist by psi^j, DFT16 over the row index (radix-2 DIF), twiddle w256^(k1*b), transpose,
-//   DFT16; cmul / cmulc with exactly one fma per component; no contraction elsewhere
-//   (the translation unit is compiled with -ffp-contract=off).
+// The arithmetic is the canonical one stated in oracle/fheaes_oracle.c ("canonical form, v2") and DESIGN.md:
+//   z_j = p_j + i p_{j+256}, j = 16a + b (lane b);  X_k = sum_j z_j e^{2 pi i j (k + 1/4)/256}, k = k1 + 16 k2
+//   pass 1   DFT16 over a with frequency offset 1/4 (radix-2 DIT; the stage twiddles e^{2 pi i (k + 1/4)/n} are the SAME in every
+//            lane: compile-time constants, no table read -- the negacyclic twist costs no pass of its own),
+//   twiddle  T[k1][b] = psi^(b (4 k1 + 1)) (cmul; the one table, 16 entries per lane, read a whole pass ahead),
+//   pass 2   transpose, plain DFT16 over b (radix-2 DIT, twiddles 1 and +-i are additions).
+//   inverse  plain conjugate DFT16, conj T, transpose, plain conjugate DFT16, conj psi^(16a) (constants).
+// Non-trivial DIT butterfly, 6 fused operations:  u = p + w q as two fma per component, v = 2p - u as one.
+// No contraction beyond the written fma (the translation unit is compiled with -ffp-contract=off).
+// Round 3: the round-2 form (twist pass + radix-2 DIF + separate twiddle pass, 460 instructions and 31 table reads per
+// transform) had the table reads of its first half on the critical path of the blind rotation: this form has 404 / 16.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "fft_consts.h"
 
 #define FHE_N 512
 #ifndef FFT_XPOSE_PRIO
 #define FFT_XPOSE_PRIO 2   /* wave priority while a transpose's LDS writes/reads are being issued (measured -0.7 %) */
 #endif
+#ifndef FFT_CHUNK
+#define FFT_CHUNK 4            /* butterflies issued together (see dft16) */
+#endif
+#ifndef FFT_CHUNK_BARRIERS
+#define FFT_CHUNK_BARRIERS 1
+#endif
 #define FHE_H 256
 #define GROUP_TILE_BYTES 4352          /* 16 rows x 17 complex x 16 B */
 #define GROUP_TILE_DOUBLES (GROUP_TILE_BYTES / 8)
-
-struct FftConsts {           // w16^1 = (c1, s1), w16^2 = (h, h)
-    double c1, s1, h;
-};
+// the twiddle table T in LDS / HBM: entry (k1, b) at index 17 k1 + b -- the forward transform reads a COLUMN (lane b, k1 = 0..15),
+// the inverse a ROW (lane k1, b = 0..15); with rows of 17 both are conflict-free 16-byte reads
+#define FHE_TW_STRIDE 17
+#define FHE_TW_ENTRIES (16 * FHE_TW_STRIDE)
 
 __device__ __forceinline__ void cmul(double &xr, double &xi, double wr, double wi)
 {
@@ -43,50 +57,74 @@ __device__ __forceinline__ void cmulc(double &xr, double &xi, double wr, double 
     xr = re; xi = im;
 }
 
-// DFT of length 16 in registers, radix-2 DIF, natural-order output.
-// INV = false: kernel e^{+2 pi i a k / 16}; INV = true: conjugate kernel.
+// DFT of length 16 in registers, radix-2 decimation in time, natural order in and out.
+// INV = false: kernel e^{+2 pi i a (k + phi)/16}, phi = OFFSET ? 1/4 : 0; INV = true: conjugate kernel (phi = 0 only).
 // `hook(stage)` runs after butterfly stage 0..3 (a caller interleaves independent memory instructions there).
 struct FftNoHook { __device__ __forceinline__ void operator()(int) const {} };
-template <bool INV, typename Hook = FftNoHook>
-__device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], const FftConsts fc, Hook hook = Hook())
+template <bool INV, bool OFFSET, typename Hook = FftNoHook>
+__device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], Hook hook = Hook())
 {
+    static_assert(!(INV && OFFSET), "the inverse applies its untwist after the transform");
+    constexpr int BR[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};   // logical position -> register
 #pragma unroll
-    for (int half = 8; half >= 1; half >>= 1) {
-        const int step = 8 / half;
+    for (int st = 0; st < 4; ++st) {
+        const int n = 2 << st, half = n / 2;
+        // The eight butterflies of a stage, FFT_CHUNK at a time, each chunk in three steps (first fma of every u, second fma,
+        // then every v): a dependent f64 instruction issues 8 cycles after its producer, and a wave that has the SIMD to itself
+        // (the other one waiting for memory) would otherwise stand still for half of that behind every fused pair.
 #pragma unroll
-        for (int blk = 0; blk < 16; blk += 2 * half) {
+        for (int c0 = 0; c0 < 8; c0 += FFT_CHUNK) {
+            double tr[FFT_CHUNK], ti[FFT_CHUNK];
 #pragma unroll
-            for (int a = 0; a < half; ++a) {
-                const int m = a * step;
-                const int p = blk + a, q = p + half;
-                double ur = xr[p] + xr[q], ui = xi[p] + xi[q];
-                double dr = xr[p] - xr[q], di = xi[p] - xi[q];
-                xr[p] = ur; xi[p] = ui;
-                if (m == 0) { xr[q] = dr; xi[q] = di; }
-                else if (m == 4) {
-                    if (!INV) { xr[q] = -di; xi[q] = dr; }
-                    else      { xr[q] = di;  xi[q] = -dr; }
-                } else {
-                    double wr, wi;
-                    if (m == 1)      { wr = fc.c1;  wi = fc.s1; }
-                    else if (m == 2) { wr = fc.h;   wi = fc.h;  }
-                    else if (m == 3) { wr = fc.s1;  wi = fc.c1; }
-                    else if (m == 5) { wr = -fc.s1; wi = fc.c1; }
-                    else if (m == 6) { wr = -fc.h;  wi = fc.h;  }
-                    else             { wr = -fc.c1; wi = fc.s1; }
-                    if (!INV) cmul(dr, di, wr, wi); else cmulc(dr, di, wr, wi);
-                    xr[q] = dr; xi[q] = di;
+            for (int j = 0; j < FFT_CHUNK; ++j) {
+                const int i = c0 + j, blk = (i / half) * n, k = i % half;
+                const int e = OFFSET ? (64 * k + 16) / n : 64 * k / n;      // twiddle psi^(16 e), e in 0..31
+                const int P = BR[blk + k], Q = BR[blk + k + half];
+                if (e != 0 && e != 16) {
+                    const double c = FHE_PSI16_RE[e];
+                    tr[j] = __builtin_fma(c, xr[Q], xr[P]);
+                    ti[j] = __builtin_fma(c, xi[Q], xi[P]);
                 }
             }
+            if (FFT_CHUNK_BARRIERS) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < FFT_CHUNK; ++j) {
+                const int i = c0 + j, blk = (i / half) * n, k = i % half;
+                const int e = OFFSET ? (64 * k + 16) / n : 64 * k / n;
+                const int Q = BR[blk + k + half];
+                if (e != 0 && e != 16) {
+                    const double s = INV ? -FHE_PSI16_IM[e] : FHE_PSI16_IM[e];
+                    tr[j] = __builtin_fma(-s, xi[Q], tr[j]);
+                    ti[j] = __builtin_fma(s, xr[Q], ti[j]);
+                }
+            }
+            if (FFT_CHUNK_BARRIERS) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < FFT_CHUNK; ++j) {
+                const int i = c0 + j, blk = (i / half) * n, k = i % half;
+                const int e = OFFSET ? (64 * k + 16) / n : 64 * k / n;
+                const int P = BR[blk + k], Q = BR[blk + k + half];
+                const double pr = xr[P], pi = xi[P], qr = xr[Q], qi = xi[Q];
+                if (e == 0) {
+                    xr[P] = pr + qr; xi[P] = pi + qi; xr[Q] = pr - qr; xi[Q] = pi - qi;
+                } else if (e == 16) {                                        // w = +i (forward), -i (inverse)
+                    if (!INV) { xr[P] = pr - qi; xi[P] = pi + qr; xr[Q] = pr + qi; xi[Q] = pi - qr; }
+                    else      { xr[P] = pr + qi; xi[P] = pi - qr; xr[Q] = pr - qi; xi[Q] = pi + qr; }
+                } else {                                                     // u = p + w q (in tr/ti), v = 2p - u
+                    xr[Q] = __builtin_fma(2.0, pr, -tr[j]);
+                    xi[Q] = __builtin_fma(2.0, pi, -ti[j]);
+                    xr[P] = tr[j]; xi[P] = ti[j];
+                }
+            }
+            if (FFT_CHUNK_BARRIERS) __builtin_amdgcn_sched_barrier(0);
         }
-        hook(half == 8 ? 0 : half == 4 ? 1 : half == 2 ? 2 : 3);
+        hook(st);
     }
-    // bit-reversal to natural order (compile-time register renaming)
+    // logical position k lives in register BR[k]: rename to natural order (compile-time register renaming)
 #define FFT_SWAP(i, j) { double t0 = xr[i]; xr[i] = xr[j]; xr[j] = t0; double t1 = xi[i]; xi[i] = xi[j]; xi[j] = t1; }
     FFT_SWAP(1, 8) FFT_SWAP(2, 4) FFT_SWAP(3, 12) FFT_SWAP(5, 10) FFT_SWAP(7, 14) FFT_SWAP(11, 13)
 #undef FFT_SWAP
 }
-
 // LDS visibility between the lanes of ONE wavefront (a group never spans wavefronts).
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -126,65 +164,8 @@ __device__ __forceinline__ void group_transpose(double (&xr)[16], double (&xi)[1
 #endif
 }
 
-// Forward negacyclic transform.  In: xr[a] = p[16a+b], xi[a] = p[256+16a+b] (already doubles).
-// Out: lane k1 (= b) holds X[k1 + 16*k2] in (xr[k2], xi[k2]).
-// psi: LDS table psi[j] (j < 256) as double2; tw: LDS table tw[k1*16+b] = w256^(k1*b).
-// Split in two halves: the head touches only registers and the read-only tables, the tail is the
-// first to write the group's tile (a caller may put a workgroup barrier between them).
-__device__ __forceinline__ void nega_fwd_head(double (&xr)[16], double (&xi)[16], const double2 *psi, const double2 *tw,
-                                              int b, const FftConsts fc)
-{
-#pragma unroll
-    for (int a = 0; a < 16; ++a) {
-        double2 w = psi[16 * a + b];
-        cmul(xr[a], xi[a], w.x, w.y);
-    }
-    dft16<false>(xr, xi, fc);
-#pragma unroll
-    for (int k1 = 1; k1 < 16; ++k1) {
-        double2 w = tw[16 * k1 + b];
-        cmul(xr[k1], xi[k1], w.x, w.y);
-    }
-}
-
-__device__ __forceinline__ void nega_fwd_tail(double (&xr)[16], double (&xi)[16], double *tile, int b, const FftConsts fc)
-{
-    group_transpose(xr, xi, tile, b);
-    dft16<false>(xr, xi, fc);
-}
-
-__device__ __forceinline__ void nega_fwd(double (&xr)[16], double (&xi)[16], const double2 *psi, const double2 *tw,
-                                         double *tile, int b, const FftConsts fc)
-{
-    nega_fwd_head(xr, xi, psi, tw, b, fc);
-    nega_fwd_tail(xr, xi, tile, b, fc);
-}
-
-// Inverse (unscaled, untwisted by conj psi).  In: lane k1 holds F[k1 + 16*k2] in index k2.
-// Out: xr[a] = Re z[16a+b] * conj(psi), xi[a] = Im (i.e. real values for coefficients 16a+b and 256+16a+b),
-// still multiplied by 256.
-__device__ __forceinline__ void nega_inv(double (&xr)[16], double (&xi)[16], const double2 *psi, const double2 *tw,
-                                         double *tile, int b, const FftConsts fc)
-{
-    dft16<true>(xr, xi, fc);
-#pragma unroll
-    for (int c = 1; c < 16; ++c) {
-        double2 w = tw[16 * c + b];
-        cmulc(xr[c], xi[c], w.x, w.y);
-    }
-    group_transpose(xr, xi, tile, b);
-    dft16<true>(xr, xi, fc);
-#pragma unroll
-    for (int a = 0; a < 16; ++a) {
-        double2 w = psi[16 * a + b];
-        cmulc(xr[a], xi[a], w.x, w.y);
-    }
-}
-
-// ---- the same transforms with the table reads batched -----------------------------------------------------------------
-// With one or two waves per SIMD nothing hides an LDS round trip but the wave's own instruction stream, and the compiler
-// keeps a single table read in flight when registers are tight (each of the 31 reads of a transform then exposes ~100
-// cycles).  These forms read eight table entries at a time into a buffer, one step ahead of their use.  Identical arithmetic.
+// Table reads in batches of eight, issued a whole pass ahead of their use: with one or two waves per SIMD nothing hides an LDS
+// round trip but the wave's own instruction stream.
 __device__ __forceinline__ void fft_tw_load8(double2 (&w)[8], const double2 *tab, int base, int stride)
 {
 #pragma unroll
@@ -198,57 +179,97 @@ __device__ __forceinline__ void fft_tw_mul(double *xr, double *xi, const double2
         if (!CONJ) cmul(xr[k], xi[k], w[k].x, w[k].y); else cmulc(xr[k], xi[k], w[k].x, w[k].y);
     }
 }
-
-// forward: w0 must already hold psi[16a + b], a = 0..7 (fft_tw_load8(w0, psi, b, 16), issued before the digits were made)
-__device__ __forceinline__ void nega_fwd_batched(double (&xr)[16], double (&xi)[16], double2 (&w0)[8], double2 (&w1)[8], const double2 *psi,
-                                                 const double2 *tw, double *tile, int b, const FftConsts fc)
+// the forward transform's table column of lane b: w0 = T[0..7][b], w1 = T[8..15][b]
+__device__ __forceinline__ void fft_fwd_table(double2 (&w0)[8], double2 (&w1)[8], const double2 *tw, int b)
 {
-    fft_tw_load8(w1, psi, 128 + b, 16);                 // a = 8..15
+    fft_tw_load8(w0, tw, b, FHE_TW_STRIDE);
+    fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + b, FHE_TW_STRIDE);
+}
+// the inverse transform's table row of lane k1: w0 = T[k1][0..7] (entry 0 unused), w1 = T[k1][8..15]
+__device__ __forceinline__ void fft_inv_table(double2 (&w0)[8], double2 (&w1)[8], const double2 *tw, int k1)
+{
+    fft_tw_load8(w0, tw, FHE_TW_STRIDE * k1, 1);
+    fft_tw_load8(w1, tw, FHE_TW_STRIDE * k1 + 8, 1);
+}
+
+// Forward negacyclic transform.  In: xr[a] = p[16a+b], xi[a] = p[256+16a+b] (already doubles), lane b.
+// Out: lane k1 (= b) holds X[k1 + 16*k2] in (xr[k2], xi[k2]).
+// Split in two halves: the head touches only registers (and the table entries the caller has read with fft_fwd_table), the
+// tail is the first to write the group's tile (a caller may put a workgroup barrier between them).
+__device__ __forceinline__ void nega_fwd_head(double (&xr)[16], double (&xi)[16], const double2 (&w0)[8], const double2 (&w1)[8])
+{
+    dft16<false, true>(xr, xi);
     __builtin_amdgcn_sched_barrier(0);
     fft_tw_mul<false, 8>(xr, xi, w0);
-    __builtin_amdgcn_sched_barrier(0);
-    fft_tw_load8(w0, tw, 16 + b, 16);                   // w256^(k1 b), k1 = 1..8
-    __builtin_amdgcn_sched_barrier(0);
     fft_tw_mul<false, 8>(xr + 8, xi + 8, w1);
-    __builtin_amdgcn_sched_barrier(0);
-    fft_tw_load8(w1, tw, 128 + b, 16);                  // k1 = 8..15 (entry 0 unused)
-    __builtin_amdgcn_sched_barrier(0);
-    dft16<false>(xr, xi, fc);
-    __builtin_amdgcn_sched_barrier(0);
-    fft_tw_mul<false, 8>(xr + 1, xi + 1, w0);
-    fft_tw_mul<false, 8>(xr + 8, xi + 8, w1, 1);
-    nega_fwd_tail(xr, xi, tile, b, fc);
 }
 
-__device__ __forceinline__ void nega_inv_batched(double (&xr)[16], double (&xi)[16], double2 (&w0)[8], double2 (&w1)[8], const double2 *psi,
-                                                 const double2 *tw, double *tile, int b, const FftConsts fc)
+__device__ __forceinline__ void nega_fwd_tail(double (&xr)[16], double (&xi)[16], double *tile, int b)
 {
-    fft_tw_load8(w0, tw, 16 + b, 16);                   // k1 = 1..8
-    fft_tw_load8(w1, tw, 128 + b, 16);                  // k1 = 8..15
-    __builtin_amdgcn_sched_barrier(0);
-    dft16<true>(xr, xi, fc);
-    __builtin_amdgcn_sched_barrier(0);
-    fft_tw_mul<true, 8>(xr + 1, xi + 1, w0);
-    fft_tw_mul<true, 8>(xr + 8, xi + 8, w1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    fft_tw_load8(w0, psi, b, 16);
-    fft_tw_load8(w1, psi, 128 + b, 16);
-    __builtin_amdgcn_sched_barrier(0);
     group_transpose(xr, xi, tile, b);
-    dft16<true>(xr, xi, fc);
-    __builtin_amdgcn_sched_barrier(0);
-    fft_tw_mul<true, 8>(xr, xi, w0);
-    fft_tw_mul<true, 8>(xr + 8, xi + 8, w1);
+    dft16<false, false>(xr, xi);
 }
 
-__device__ __forceinline__ uint64_t torus_from_double(double v)
+__device__ __forceinline__ void nega_fwd(double (&xr)[16], double (&xi)[16], const double2 *tw, double *tile, int b)
 {
+    double2 w0[8], w1[8];
+    fft_fwd_table(w0, w1, tw, b);
+    __builtin_amdgcn_sched_barrier(0);
+    nega_fwd_head(xr, xi, w0, w1);
+    nega_fwd_tail(xr, xi, tile, b);
+}
+
+// Inverse (unscaled).  In: lane k1 holds F[k1 + 16*k2] in index k2.
+// Out: xr[a], xi[a] = the real values of coefficients 16a+b and 256+16a+b (lane b), still multiplied by 256.
+__device__ __forceinline__ void nega_inv(double (&xr)[16], double (&xi)[16], const double2 *tw, double *tile, int b)
+{
+    double2 w0[8], w1[8];
+    fft_inv_table(w0, w1, tw, b);
+    __builtin_amdgcn_sched_barrier(0);
+    dft16<true, false>(xr, xi);
+    __builtin_amdgcn_sched_barrier(0);
+    fft_tw_mul<true, 8>(xr, xi, w0, 1);
+    fft_tw_mul<true, 8>(xr + 8, xi + 8, w1);
+    group_transpose(xr, xi, tile, b);
+    dft16<true, false>(xr, xi);
+#pragma unroll
+    for (int a = 1; a < 16; ++a) cmulc(xr[a], xi[a], FHE_PSI16_RE[a], FHE_PSI16_IM[a]);
+}
+
+// Back-conversion of an inverse-transform output to the torus.  Canonical definition (oracle/fheaes_oracle.c):
+//   w = v * 2^-72; w -= rint(w); r = rint(w * 2^64); result = (uint64)(int64) r   (r = +2^63 wraps to -2^63).
+// Computed here without a 64-bit float->integer conversion.  With H = rint(w' * 2^32) and l = rint((w' - H 2^-32) * 2^64)
+// one has r = H * 2^32 + l exactly (H * 2^32 is an even integer, so the tie rule is preserved), and both roundings come out
+// of magic-number additions: a double in [2^20, 2^21) has ulp 2^-32, one in [2^-12, 2^-11) ulp 2^-64, so the low mantissa
+// bits of  w' + 1.5 * 2^20  and of  (w' - H 2^-32) + 1.5 * 2^-12  are H and l as two's complement integers.
+// 7 f64 instructions + 2 integer ones against 13 + 3 for the compiler's expansion of the definition; identical for every
+// double (checked against the definition on the CPU, 6e7 values around the tie / wrap / tiny cases).
+// torus_acc(acc, v) = acc + torus_from_double(v).
+typedef uint32_t fhe_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint64_t torus_acc(uint64_t acc, double v)
+{
+#ifdef FHE_TORUS_CONV_OLD
     double w = v * 0x1p-72;
     w -= __builtin_rint(w);
     double r = __builtin_rint(w * 0x1p64);
     if (r >= 0x1p63) r -= 0x1p64;
-    return (uint64_t)(long long)r;      // (a hand-split floor/fma conversion measured 5 % slower than the compiler's)
+    return acc + (uint64_t)(long long)r;
+#else
+    double w = v * 0x1p-72;
+    w -= __builtin_rint(w);                                  // exact, |w| <= 1/2
+    const double C_HI = 0x1.8p20, C_LO = 0x1.8p-12;
+    const double mh = w + C_HI;                              // C_HI + rint(w * 2^32) * 2^-32
+    const double hf = mh - C_HI;
+    const double lt = w - hf;                                // exact, |lt| <= 2^-33
+    const double ml = lt + C_LO;                             // C_LO + rint(lt * 2^64) * 2^-64
+    const fhe_u32x2 bh = __builtin_bit_cast(fhe_u32x2, mh), bl = __builtin_bit_cast(fhe_u32x2, ml);
+    fhe_u32x2 r;
+    r[0] = bl[0];
+    r[1] = bh[0] + bl[1] + 0xC0C80000u;                      // - 0x3F380000: the exponent word of C_LO
+    return acc + __builtin_bit_cast(uint64_t, r);
+#endif
 }
+__device__ __forceinline__ uint64_t torus_from_double(double v) { return torus_acc(0, v); }
 
 __device__ __forceinline__ double double_from_torus(uint64_t x) { return (double)(long long)x; }
 
@@ -275,9 +296,55 @@ __device__ __forceinline__ void decompose_all(uint64_t x, int (&dig)[LEVELS])
 // Streaming form used by the external product: the first call consumes x and leaves a 32-bit
 // state; later calls peel one level each (least significant level first).  Requires
 // BASE_LOG*(LEVELS-1) <= 32.
+//
+// The tfhe-rs rule  d = st & (B-1); st >>= b; carry = (((d-1)|st)&d) >> (b-1); st += carry; d -= carry << b
+// says: carry iff d > B/2, or d == B/2 and the next digit's top bit is set.  With e = bit (2b-1) of the state that is
+// "d + (B/2 - 1) + e >= B", i.e. ONE addition whose overflow out of the low digit is the carry:
+//   t = st + (B/2 - 1) + e;   st' = t >> b;   digit = st - (st' << b)
+// (5 instructions per digit instead of 9; same digits for every input).
+template <int BASE_LOG>
+__device__ __forceinline__ int decompose_next(uint32_t &state)
+{
+#ifdef FHE_PEEL_OLD
+    uint32_t d = state & ((1u << BASE_LOG) - 1);
+    uint32_t st = state >> BASE_LOG;
+    uint32_t carry = (((d - 1) | st) & d) >> (BASE_LOG - 1);
+    state = st + carry;
+    return (int)d - (int)(carry << BASE_LOG);
+#else
+    const uint32_t e = (state >> (2 * BASE_LOG - 1)) & 1u;
+    const uint32_t t = state + ((1u << (BASE_LOG - 1)) - 1u) + e;
+    const int digit = (int)(state - (t & ~((1u << BASE_LOG) - 1u)));
+    state = t >> BASE_LOG;
+    return digit;
+#endif
+}
+
+// First peel from xr = x + 2^(R-1) (the rounding addition already done by the caller, wrapping), R = 64 - BASE_LOG*LEVELS.
+template <int BASE_LOG, int LEVELS>
+__device__ __forceinline__ int decompose_first_rounded(uint64_t xr, uint32_t &state)
+{
+    constexpr int R = 64 - BASE_LOG * LEVELS;
+    const uint32_t d = (uint32_t)(xr >> R) & ((1u << BASE_LOG) - 1u);
+    if (LEVELS == 1) {
+        // no digit above this one: the tie d == B/2 stays +B/2
+        const uint32_t t = d + ((1u << (BASE_LOG - 1)) - 1u);
+        state = 0;
+        return (int)(d - (t & ~((1u << BASE_LOG) - 1u)));
+    }
+    const uint32_t st = (uint32_t)(xr >> (R + BASE_LOG));                          // the remaining LEVELS-1 digits (32 bits at most)
+    const uint32_t e = (st >> (BASE_LOG - 1)) & 1u;
+    const uint32_t t = d + ((1u << (BASE_LOG - 1)) - 1u) + e;
+    uint32_t s2 = st + (t >> BASE_LOG);
+    if (BASE_LOG * (LEVELS - 1) < 32) s2 &= (uint32_t)((1ULL << (BASE_LOG * (LEVELS - 1))) - 1);
+    state = s2;
+    return (int)(d - (t & ~((1u << BASE_LOG) - 1u)));
+}
+
 template <int BASE_LOG, int LEVELS>
 __device__ __forceinline__ int decompose_first(uint64_t x, uint32_t &state)
 {
+#ifdef FHE_PEEL_OLD
     constexpr int R = 64 - BASE_LOG * LEVELS;
     uint64_t y = (x >> R) + ((x >> (R - 1)) & 1);
     uint32_t d = (uint32_t)y & ((1u << BASE_LOG) - 1);
@@ -287,14 +354,7 @@ __device__ __forceinline__ int decompose_first(uint64_t x, uint32_t &state)
     uint32_t carry = (((d - 1) | st) & d) >> (BASE_LOG - 1);
     state = st + carry;
     return (int)d - (int)(carry << BASE_LOG);
-}
-
-template <int BASE_LOG>
-__device__ __forceinline__ int decompose_next(uint32_t &state)
-{
-    uint32_t d = state & ((1u << BASE_LOG) - 1);
-    uint32_t st = state >> BASE_LOG;
-    uint32_t carry = (((d - 1) | st) & d) >> (BASE_LOG - 1);
-    state = st + carry;
-    return (int)d - (int)(carry << BASE_LOG);
+#else
+    return decompose_first_rounded<BASE_LOG, LEVELS>(x + (1ULL << (64 - BASE_LOG * LEVELS - 1)), state);
+#endif
 }

@@ -35,10 +35,15 @@
                               20 -> 268, 25 -> 297 (spills past 18); some of them ahead of the tiles-free barrier, or the late ones
                               between the digit stores: no gain. */
 #endif
-#ifndef BR16_PARK_NT
-#define BR16_PARK_NT 0     /* nontemporal parking stores/loads (measured: see DESIGN.md) */
+#ifndef BR16_PARK_AUX_ST
+#define BR16_PARK_AUX_ST 0 /* cache policy bits of the parking stores (1 = sc0, 2 = nt, 16 = sc1; measured: see DESIGN.md) */
 #endif
-#define BR16_PARK_WORDS_PER_WG (16 * EP_THREADS * 2 * 2)   /* 16 chunks of 32 bytes per thread: lo[a], hi[a] pairs */
+#ifndef BR16_PARK_AUX_LD
+#define BR16_PARK_AUX_LD 2 /* ... and of the parking loads.  nt: the reload is the line's last use, it should not displace GGSW rows in L2.
+                              Measured per 16,384-bit launch (rocprofv3 FETCH_SIZE x 2, same box): loads default 775 GB / 239 ms, nt 527 GB /
+                              235 ms; stores sc1 or sc0+sc1 on top: no further change; nt STORES: 242-247 ms (slower), whatever the loads do */
+#endif
+#define BR16_PARK_WORDS_PER_WG (16 * EP_THREADS * 2)       /* 16 chunks of 16 bytes per thread (lo[a], hi[a]): 64 KB per workgroup */
 
 __device__ __forceinline__ int br16_opaque_tid()
 {
@@ -55,20 +60,17 @@ template <int K1, int LEVELS, int BASE_LOG, int R>
 __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double *lds_all, const uint64_t inst0)
 {
     static_assert(R * K1 <= EP_GROUPS, "too many polynomials for 16 lane groups");
-    // twiddle tables first: their addresses then fit the 16-bit offset field of the LDS instructions
-    double2 *psi = reinterpret_cast<double2 *>(lds_all);
-    double2 *tw = psi + FHE_H;
-    double *lds = lds_all + 2 * 2 * FHE_H;                        // the 16 group tiles
+    // the twiddle table first: its addresses then fit the 16-bit offset field of the LDS instructions
+    double2 *tw = reinterpret_cast<double2 *>(lds_all);
+    double *lds = lds_all + 2 * FHE_TW_ENTRIES;                   // the 16 group tiles
 
     const int tid = threadIdx.x;
     const int g = tid >> 4, b = tid & 15;
     const bool owner = g < R * K1;
     const int r_own = owner ? g / K1 : R - 1;
     const int p_own = owner ? g % K1 : K1 - 1;
-    const FftConsts fc = A.fc;
 
-    psi[tid] = A.psi[tid];
-    tw[tid] = A.tw[tid];
+    ep_load_table(tw, A.tw);
 
     uint64_t inst = inst0 + r_own;
     const bool valid = inst < A.count;
@@ -76,6 +78,10 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
     const uint64_t *lwe = A.lwe_in + inst * (uint64_t)(A.iters + 1);
 
     // ---- accumulator init (coefficients 16a+b and 256+16a+b in lane b) ------------------------------------------
+    // The registers, the LDS tile and the parking slab hold the NEGATED accumulator (nacc = -acc): the rotation then needs
+    //   d = acc * X^t - acc = (+-)(-nacc[src]) + nacc[j],
+    // i.e. a conditional two's complement (xor with a mask; its "+1" rides on the decomposition's rounding constant) and ONE
+    // 64-bit addition per coefficient, instead of a negate, a select and a subtraction with their carry chains.
     uint64_t lo[16], hi[16];
     {
         const int bt = mod_switch_1024(lwe[A.iters] + A.body_shift);
@@ -84,13 +90,15 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
         for (int a = 0; a < 16; ++a) {
             int j0 = 16 * a + b, j1 = j0 + 256;
             int e0 = ((j0 - t) & 511) + t, e1 = ((j1 - t) & 511) + t;
-            uint64_t v0 = ((e0 >> 9) & 1) ? (uint64_t)0 - A.tv_const : A.tv_const;
-            uint64_t v1 = ((e1 >> 9) & 1) ? (uint64_t)0 - A.tv_const : A.tv_const;
+            uint64_t v0 = ((e0 >> 9) & 1) ? A.tv_const : (uint64_t)0 - A.tv_const;      // negated (see above)
+            uint64_t v1 = ((e1 >> 9) & 1) ? A.tv_const : (uint64_t)0 - A.tv_const;
             lo[a] = (p_own == K1 - 1) ? v0 : 0;
             hi[a] = (p_own == K1 - 1) ? v1 : 0;
         }
     }
-    ulonglong2 *park = reinterpret_cast<ulonglong2 *>(A.park) + (size_t)blockIdx.x * 16 * EP_THREADS;   // wave-uniform
+    // the parking slab as one raw buffer: (scalar: workgroup slab + chunk) + (16 * lane) -- no vector address arithmetic
+    const __amdgpu_buffer_rsrc_t park_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.park, 0, (int)A.park_bytes, 0x00020000);
+    const unsigned park_wg = blockIdx.x * (unsigned)(BR16_PARK_WORDS_PER_WG * 8);                       // wave-uniform
     __syncthreads();   // tables visible
 #if defined(BR16_STAGGER_SLEEP) && BR16_STAGGER_SLEEP > 0
     // developer experiment: start every second generation of workgroups a fraction of a level later, so that the two
@@ -131,28 +139,31 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             }
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
-                ulonglong2 v; v.x = lo[a]; v.y = hi[a];
-#if BR16_PARK_NT
-                typedef unsigned long long br16_u64x2 __attribute__((ext_vector_type(2)));
-                br16_u64x2 nv; nv[0] = v.x; nv[1] = v.y;
-                __builtin_nontemporal_store(nv, reinterpret_cast<br16_u64x2 *>(park + a * EP_THREADS) + (unsigned)tq);
-#else
-                (park + a * EP_THREADS)[(unsigned)tq] = v;
-#endif
+                ep_u32x4 v;
+                v[0] = (uint32_t)lo[a]; v[1] = (uint32_t)(lo[a] >> 32); v[2] = (uint32_t)hi[a]; v[3] = (uint32_t)(hi[a] >> 32);
+                __builtin_amdgcn_raw_buffer_store_b128(v, park_rsrc, (unsigned)tq * 16u, park_wg + (unsigned)a * (EP_THREADS * 16), BR16_PARK_AUX_ST);
             }
             wave_lds_sync();
-            fft_tw_load8(w0, psi, bq_, 16);                       // psi^(16a+b), a = 0..7: lands during the rotation
+            fft_tw_load8(w0, tw, bq_, FHE_TW_STRIDE);             // first half of the lane's table column (T[0..7][b]): lands during the rotation
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
-                int j0 = 16 * a + bq_;
-                int s0 = (j0 - t) & 511, s1 = s0 ^ 256;
-                uint64_t v0 = stage[s0], v1 = stage[s1];
-                if (((s0 + t) >> 9) & 1) v0 = (uint64_t)0 - v0;
-                if (((s1 + t) >> 9) & 1) v1 = (uint64_t)0 - v1;
-                v0 -= lo[a]; v1 -= hi[a];
-                xr[a] = (double)decompose_first<BASE_LOG, LEVELS>(v0, st_lo[a]);
-                xi[a] = (double)decompose_first<BASE_LOG, LEVELS>(v1, st_hi[a]);
+                // coefficient j of acc * X^t is acc[(j - t) mod 512], negated iff bit 9 of (j - t) is set (t < 1024)
+                const int u0 = 16 * a + bq_ - t, u1 = u0 + 256;
+                const int s0 = u0 & 511, s1 = s0 ^ 256;
+                const fhe_u32x2 v0 = *reinterpret_cast<const fhe_u32x2 *>(stage + s0), v1 = *reinterpret_cast<const fhe_u32x2 *>(stage + s1);   // -acc[src]
+                // mask = ~0: no wrap, take +acc[src] = ~v + 1; mask = 0: wrapped, take -acc[src] = v.  The "+1" joins the rounding
+                // constant 2^(R-1) of the decomposition (one 32-bit subtraction), so each coefficient costs two xor and two 64-bit adds.
+                const uint32_t m0 = (uint32_t)((u0 >> 9) & 1) - 1u, m1 = (uint32_t)((u1 >> 9) & 1) - 1u;
+                constexpr uint64_t RND = 1ull << (64 - BASE_LOG * LEVELS - 1);
+                static_assert(RND < (1ull << 31), "rounding constant must fit the low word");
+                fhe_u32x2 w0, w1, k0, k1;
+                w0[0] = v0[0] ^ m0; w0[1] = v0[1] ^ m0; w1[0] = v1[0] ^ m1; w1[1] = v1[1] ^ m1;
+                k0[0] = (uint32_t)RND - m0; k0[1] = 0; k1[0] = (uint32_t)RND - m1; k1[1] = 0;
+                const uint64_t x0 = (__builtin_bit_cast(uint64_t, w0) + lo[a]) + __builtin_bit_cast(uint64_t, k0);   // d + rounding constant
+                const uint64_t x1 = (__builtin_bit_cast(uint64_t, w1) + hi[a]) + __builtin_bit_cast(uint64_t, k1);
+                xr[a] = (double)decompose_first_rounded<BASE_LOG, LEVELS>(x0, st_lo[a]);
+                xi[a] = (double)decompose_first_rounded<BASE_LOG, LEVELS>(x1, st_hi[a]);
                 if ((a & (EP_ROT_CHUNK - 1)) == EP_ROT_CHUNK - 1) __builtin_amdgcn_sched_barrier(0);
             }
             wave_lds_sync();
@@ -165,30 +176,21 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 #pragma unroll
             for (int c = 0; c < K1; ++c) { fr[r][c] = 0.0; fi[r][c] = 0.0; }
 
-        // One decomposition level.  On entry w0 holds (or is about to receive) psi^(16a+b), a = 0..7, and xr/xi the digits.
+        // One decomposition level.  On entry w0 / w1 hold (or are about to receive) the lane's table column, and xr/xi the digits.
         auto level_body = [&](const int l, const bool tiles_busy) {
             const int tq = br16_opaque_tid();
             const int bq_ = tq & 15;
             double *tile = lds + (tq >> 4) * GROUP_TILE_DOUBLES;
-            // ---- forward transform: fold + twist, DFT16, twiddle, transpose, DFT16 (fft_dev.h's nega_fwd, with the
-            //      table reads batched eight at a time and issued one step ahead) ------------------------------------
-            fft_tw_load8(w1, psi, 128 + bq_, 16);                  // a = 8..15
-            __builtin_amdgcn_sched_barrier(0);
-            fft_tw_mul<false, 8>(xr, xi, w0);
-            __builtin_amdgcn_sched_barrier(0);
-            fft_tw_load8(w0, tw, 16 + bq_, 16);                    // w256^(k1 b), k1 = 1..8
-            __builtin_amdgcn_sched_barrier(0);
-            fft_tw_mul<false, 8>(xr + 8, xi + 8, w1);
-            __builtin_amdgcn_sched_barrier(0);
-            fft_tw_load8(w1, tw, 128 + bq_, 16);                   // k1 = 8..15 (entry 0 unused)
+            // ---- forward transform (fft_dev.h): pass 1 (frequency offset 1/4, constants only), twiddle by the table column read a
+            //      whole decomposition step ago, transpose, pass 2 ---------------------------------------------------------------
+            fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE);   // second half of the column (T[8..15][b]): lands during pass 1
             __builtin_amdgcn_sched_barrier(0);
 #ifndef BR16_ABL_NOFFT
-            dft16<false>(xr, xi, fc);
+            dft16<false, true>(xr, xi);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            fft_tw_mul<false, 8>(xr + 1, xi + 1, w0);
-#pragma unroll
-            for (int k = 1; k < 8; ++k) cmul(xr[8 + k], xi[8 + k], w1[k].x, w1[k].y);
+            fft_tw_mul<false, 8>(xr, xi, w0);
+            fft_tw_mul<false, 8>(xr + 8, xi + 8, w1);
             EP_STAMP(2);
             const unsigned gl_bytes = g_bytes + (unsigned)l * (K1 * K1 * FHE_H * 16);   // scalar; the lane adds 16 * point
             double2 bm[K1][K1];
@@ -217,7 +219,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             group_transpose(xr, xi, tile, bq_);
             key_rows(0, NE);
 #elif defined(BR16_ABL_NOXPOSE)
-            dft16<false>(xr, xi, fc);
+            dft16<false, false>(xr, xi);
             key_rows(0, NE);
 #else
             {
@@ -242,7 +244,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 #if FFT_XPOSE_PRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
-                dft16<false>(xr, xi, fc, [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } });
+                dft16<false, false>(xr, xi, [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } });
             }
 #endif
             EP_STAMP(4);
@@ -301,7 +303,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
         for (int l = LEVELS - 2; l >= 0; --l) {
             {
                 const int tq = br16_opaque_tid();
-                fft_tw_load8(w0, psi, tq & 15, 16);               // lands during the decomposition step
+                fft_tw_load8(w0, tw, tq & 15, FHE_TW_STRIDE);     // lands during the decomposition step
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -320,13 +322,9 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
         ulonglong2 pk[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-#if BR16_PARK_NT
-            typedef unsigned long long br16_u64x2 __attribute__((ext_vector_type(2)));
-            br16_u64x2 nv = __builtin_nontemporal_load(reinterpret_cast<const br16_u64x2 *>(park + a * EP_THREADS) + (unsigned)tq);
-            pk[a].x = nv[0]; pk[a].y = nv[1];
-#else
-            pk[a] = (park + a * EP_THREADS)[(unsigned)tq];
-#endif
+            const ep_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(park_rsrc, (unsigned)tq * 16u, park_wg + (unsigned)a * (EP_THREADS * 16), BR16_PARK_AUX_LD);
+            pk[a].x = ((unsigned long long)v[1] << 32) | v[0];
+            pk[a].y = ((unsigned long long)v[3] << 32) | v[2];
         }
         // ---- products back to the owning groups, inverse transform, accumulate --------------------------------------
         wg_barrier_lds_only();       // every thread is done reading the last level's digits from the tiles
@@ -343,30 +341,24 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ + 16 * k2));
             xr[k2] = v.x; xi[k2] = v.y;
         }
-        fft_tw_load8(w0, tw, 16 + bq_, 16);                       // k1 = 1..8
-        fft_tw_load8(w1, tw, 128 + bq_, 16);                      // k1 = 8..15
+        fft_inv_table(w0, w1, tw, bq_);                            // the table row of this lane
         wave_lds_sync();
         EP_STAMP(8);
-        // inverse transform (fft_dev.h's nega_inv, table reads batched and issued a step ahead)
-        dft16<true>(xr, xi, fc);
+        // inverse transform (fft_dev.h's nega_inv, the table row read a pass ahead)
+        dft16<true, false>(xr, xi);
         __builtin_amdgcn_sched_barrier(0);
-        fft_tw_mul<true, 8>(xr + 1, xi + 1, w0);
-#pragma unroll
-        for (int k = 1; k < 8; ++k) cmulc(xr[8 + k], xi[8 + k], w1[k].x, w1[k].y);
-        __builtin_amdgcn_sched_barrier(0);
-        fft_tw_load8(w0, psi, bq_, 16);
-        fft_tw_load8(w1, psi, 128 + bq_, 16);
+        fft_tw_mul<true, 8>(xr, xi, w0, 1);
+        fft_tw_mul<true, 8>(xr + 8, xi + 8, w1);
         __builtin_amdgcn_sched_barrier(0);
         group_transpose(xr, xi, tile, bq_);
-        dft16<true>(xr, xi, fc);
-        __builtin_amdgcn_sched_barrier(0);
-        fft_tw_mul<true, 8>(xr, xi, w0);
-        fft_tw_mul<true, 8>(xr + 8, xi + 8, w1);
+        dft16<true, false>(xr, xi);
+#pragma unroll
+        for (int a = 1; a < 16; ++a) cmulc(xr[a], xi[a], FHE_PSI16_RE[a], FHE_PSI16_IM[a]);
         EP_STAMP(9);
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            lo[a] = pk[a].x + torus_from_double(xr[a]);
-            hi[a] = pk[a].y + torus_from_double(xi[a]);
+            lo[a] = torus_acc(pk[a].x, -xr[a]);               // negated accumulator: -(acc + r) = -acc + (-r)
+            hi[a] = torus_acc(pk[a].y, -xi[a]);
         }
         EP_STAMP(10);
     }
@@ -376,19 +368,27 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 #endif
 
     // ---- sample extract coefficient 0 ---------------------------------------------------------------
-    if (owner && valid) {
-        const uint64_t big = (uint64_t)(K1 - 1) * FHE_N;
-        uint64_t *o = A.out + inst * (big + 1);
-        if (p_own < K1 - 1) {
-            uint64_t *om = o + (uint64_t)p_own * FHE_N;
+    // (lane roles recomputed from the opaque lane index: nothing of them stays live across the 669-iteration loop)
+    {
+        const int te = br16_opaque_tid();
+        const int ge = te >> 4, be = te & 15;
+        const bool owner_e = ge < R * K1;
+        const int re = owner_e ? ge / K1 : R - 1, pe = owner_e ? ge % K1 : K1 - 1;
+        const uint64_t inst_e = inst0 + re;
+        if (owner_e && inst_e < A.count) {
+            const uint64_t big = (uint64_t)(K1 - 1) * FHE_N;
+            uint64_t *o = A.out + inst_e * (big + 1);
+            if (pe < K1 - 1) {
+                uint64_t *om = o + (uint64_t)pe * FHE_N;
 #pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                int j0 = 16 * a + b, j1 = j0 + 256;
-                if (j0 == 0) om[0] = lo[a]; else om[FHE_N - j0] = (uint64_t)0 - lo[a];
-                om[FHE_N - j1] = (uint64_t)0 - hi[a];
+                for (int a = 0; a < 16; ++a) {
+                    int j0 = 16 * a + be, j1 = j0 + 256;
+                    if (j0 == 0) om[0] = (uint64_t)0 - lo[a]; else om[FHE_N - j0] = lo[a];      // lo/hi hold -acc
+                    om[FHE_N - j1] = hi[a];
+                }
+            } else if (be == 0) {
+                o[big] = A.post_add - lo[0];
             }
-        } else if (b == 0) {
-            o[big] = lo[0] + A.post_add;
         }
     }
 }

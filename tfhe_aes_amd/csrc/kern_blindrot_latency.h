@@ -18,7 +18,7 @@
 //     depend on data) and land during the rotation / decomposition / transform; afterwards one level (K1 rows) stays in flight;
 //   * the multiply-accumulate is split by output column over all 512 threads (3 + 2 columns), halving its length and
 //     the registers a row occupies; key rows come through raw buffer loads with scalar row offsets;
-//   * twiddle reads are batched eight at a time, one step ahead of their use (fft_dev.h, nega_*_batched);
+//   * the transform's table entries are read as one batch, a whole pass ahead of their use (fft_dev.h);
 //   * the accumulator no longer has a register copy (64 VGPRs, and the publish step with its barrier, are gone).
 // 4 workgroup barriers and 2 transform passes per iteration (11 and 6 in the throughput kernel).  Same arithmetic as
 // the throughput kernel: results are bit-identical (tests/test_gpu_stages.py::test_k2_blind_rotation covers both).
@@ -38,11 +38,10 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
     constexpr int ROWS = LEVELS * K1;
     constexpr int CA = (K1 + 1) / 2, CB = K1 - CA;        // output columns of threads 0..255 / 256..511
     static_assert(ROWS <= BL_THREADS / 16, "one lane group per digit polynomial");
-    constexpr int LDS_DOUBLES = 2 * 2 * FHE_H + ROWS * GROUP_TILE_DOUBLES + K1 * FHE_N;
+    constexpr int LDS_DOUBLES = 2 * FHE_TW_ENTRIES + ROWS * GROUP_TILE_DOUBLES + K1 * FHE_N;
     __shared__ __attribute__((aligned(16))) double lds_all[LDS_DOUBLES];
-    double2 *psi = reinterpret_cast<double2 *>(lds_all);                                       // tables first: 16-bit offsets reach them
-    double2 *tw = psi + FHE_H;
-    double *lds = lds_all + 2 * 2 * FHE_H;                                                      // ROWS tiles
+    double2 *tw = reinterpret_cast<double2 *>(lds_all);                                        // table first: 16-bit offsets reach it
+    double *lds = lds_all + 2 * FHE_TW_ENTRIES;                                                 // ROWS tiles
     uint64_t *accs = reinterpret_cast<uint64_t *>(lds + ROWS * GROUP_TILE_DOUBLES);            // [K1][512]
 
     const int tid = threadIdx.x;
@@ -51,12 +50,8 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
     const bool owner = g < K1;                        // output polynomial g is inverse-transformed by this group
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: what depends on it stays in SGPRs / scalar branches
     const bool half_b = wave_id >= 4;                 // multiply-accumulate role: columns CA..K1-1 (wave-uniform)
-    const FftConsts fc = A.fc;
 
-    if (tid < FHE_H) {
-        psi[tid] = A.psi[tid];
-        tw[tid] = A.tw[tid];
-    }
+    ep_load_table(tw, A.tw);
 
     const uint64_t inst = blockIdx.x;                 // one ciphertext per workgroup, grid = count
     const uint64_t *lwe = A.lwe_in + inst * (uint64_t)(A.iters + 1);
@@ -159,11 +154,12 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
         if (transform) {
             double xr[16], xi[16];
             double2 w0[8], w1[8];
-            fft_tw_load8(w0, psi, bq_, 16);
+            fft_fwd_table(w0, w1, tw, bq_);            // lands during the coefficient reads and the first pass
 #pragma unroll
             for (int a = 0; a < 16; ++a) { xr[a] = tile[16 * a + bq_]; xi[a] = tile[256 + 16 * a + bq_]; }
             wave_lds_sync();                           // the group's lanes have their coefficients before the transform reuses the tile
-            nega_fwd_batched(xr, xi, w0, w1, psi, tw, tile, bq_, fc);
+            nega_fwd_head(xr, xi, w0, w1);
+            nega_fwd_tail(xr, xi, tile, bq_);
             EP_STAMP(2);
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
@@ -230,14 +226,13 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
         //      owner groups alone they were a third of this phase, with everyone else waiting).
         if (owner) {
             double xr[16], xi[16];
-            double2 w0[8], w1[8];
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ + 16 * k2));
                 xr[k2] = v.x; xi[k2] = v.y;
             }
             wave_lds_sync();
-            nega_inv_batched(xr, xi, w0, w1, psi, tw, tile, bq_, fc);
+            nega_inv(xr, xi, tw, tile, bq_);
             wave_lds_sync();                           // the transform's last reads of the tile are done in every lane of the group
 #pragma unroll
             for (int a = 0; a < 16; ++a) { tile[16 * a + bq_] = xr[a]; tile[256 + 16 * a + bq_] = xi[a]; }

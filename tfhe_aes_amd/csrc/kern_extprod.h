@@ -33,14 +33,18 @@
 #define EP_PREFETCH 2
 #endif
 #define EP_GROUPS 16
-#define EP_LDS_DOUBLES (EP_GROUPS * GROUP_TILE_DOUBLES + 2 * 2 * FHE_H)
+#define EP_LDS_DOUBLES (EP_GROUPS * GROUP_TILE_DOUBLES + 2 * FHE_TW_ENTRIES)
+
+// the twiddle table into LDS (272 entries, any workgroup size >= 64)
+__device__ __forceinline__ void ep_load_table(double2 *tw_lds, const double2 *tw_g)
+{
+    for (int i = threadIdx.x; i < FHE_TW_ENTRIES; i += blockDim.x) tw_lds[i] = tw_g[i];
+}
 
 struct ExtProdArgs {
     // common
     const double2 *ggsw;        // PBS: BSK Fourier [n][L][K1][K1][256]; VP: [n_inputs][bits][L][K1][K1][256]
-    const double2 *psi;         // [256] psi^j
-    const double2 *tw;          // [256] tw[k1*16+b] = w256^(k1*b)
-    FftConsts fc;
+    const double2 *tw;          // [FHE_TW_ENTRIES] tw[17 k1 + b] = psi^(b (4 k1 + 1)), the transform's one table (fft_dev.h)
     uint64_t *out;              // PBS: [m][big+1]; VP: [n_inputs][n_luts][bits][big+1]
     uint64_t count;             // PBS: ciphertexts m; VP: n_inputs * n_luts * bits instances
     uint32_t iters;             // PBS: n; VP: bits
@@ -59,6 +63,7 @@ struct ExtProdArgs {
     uint64_t lut_words;         // VP: words per (LUT, output bit) in `luts` (512, or 2^bits when a CMUX tree ran first)
     const uint64_t *glwe_in;    // VP: non-null: the accumulator starts from this GLWE [instance][K1][512] (root of the CMUX tree)
     uint64_t *park;             // kern_blindrot16.h: accumulator parking space, 64 KB per workgroup
+    uint64_t park_bytes;        //   its size (< 2^31: one raw buffer)
     uint32_t units_main;        // kern_blindrot16.h: workgroups below this index carry R ciphertexts, the others R2
 #ifdef EP_STAMPS
     unsigned long long *stamps; // developer build: per-wave cycles per phase [grid][4 waves][EP_NPH]
@@ -84,7 +89,10 @@ __device__ __forceinline__ double2 ep_key_load(__amdgpu_buffer_rsrc_t rsrc, unsi
 #define EP_NPH 12
 #define EP_STAMP(ph) do { unsigned long long t__ = __builtin_readcyclecounter(); ph_cyc[ph] += t__ - t_last; t_last = t__; } while (0)
 #else
-#define EP_STAMP(ph) do { } while (0)
+#ifndef EP_FENCE_MASK
+#define EP_FENCE_MASK 0        /* developer knob: bit ph set = the wave drains its LDS/scalar-memory counter at phase boundary ph (what a stamp does) */
+#endif
+#define EP_STAMP(ph) do { if ((EP_FENCE_MASK >> (ph)) & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
 #endif
 
 template <int K1, int LEVELS, int BASE_LOG, int R, bool VP>
@@ -95,8 +103,7 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
 {
     static_assert(R * K1 <= EP_GROUPS, "too many polynomials for 16 lane groups");
     __shared__ __attribute__((aligned(16))) double lds[EP_LDS_DOUBLES];
-    double2 *psi = reinterpret_cast<double2 *>(lds + EP_GROUPS * GROUP_TILE_DOUBLES);
-    double2 *tw = psi + FHE_H;
+    double2 *tw = reinterpret_cast<double2 *>(lds + EP_GROUPS * GROUP_TILE_DOUBLES);
 
     const int tid = threadIdx.x;
     const int g = tid >> 4, b = tid & 15;
@@ -104,10 +111,8 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
     const int r_own = owner ? g / K1 : R - 1;
     const int p_own = owner ? g % K1 : K1 - 1;
     double *tile = lds + g * GROUP_TILE_DOUBLES;
-    const FftConsts fc = A.fc;
 
-    psi[tid] = A.psi[tid];
-    tw[tid] = A.tw[tid];
+    ep_load_table(tw, A.tw);
 
     // ---- which ciphertext / instance does this group work on -------------------------------
     uint64_t inst;            // PBS: ciphertext index; VP: global instance index
@@ -221,14 +226,18 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
             // first half of the transform needs no tile; the barrier that frees the tiles (other threads
             // may still be reading the previous level's digits) sits as late as possible
 #ifndef ABL_NO_FFT
-            nega_fwd_head(xr, xi, psi, tw, b, fc);
+            {
+                double2 w0[8], w1[8];
+                fft_fwd_table(w0, w1, tw, b);
+                nega_fwd_head(xr, xi, w0, w1);
+            }
 #endif
 #ifdef EP_LATE_BARRIER
             if (tiles_busy) __syncthreads();
 #endif
             EP_STAMP(2);
 #ifndef ABL_NO_FFT
-            nega_fwd_tail(xr, xi, tile, b, fc);
+            nega_fwd_tail(xr, xi, tile, b);
 #endif
             EP_STAMP(4);
             const double2 *Gl = G + (size_t)l * K1 * K1 * FHE_H + tid;
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
         wave_lds_sync();
         EP_STAMP(8);
 #ifndef ABL_NO_FFT
-        nega_inv(xr, xi, psi, tw, tile, b, fc);
+        nega_inv(xr, xi, tw, tile, b);
 #endif
         EP_STAMP(9);
 #pragma unroll
@@ -395,8 +404,7 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
 // one decomposition level.  Not on the AES path (8- and 9-bit inputs only); it completes many_wopbs_without_padding.
 struct CmuxArgs {
     const double2 *ggsw;        // Fourier GGSWs [n_inputs][bits][K1][K1][256]
-    const double2 *psi, *tw;
-    FftConsts fc;
+    const double2 *tw;          // the transform's table (see ExtProdArgs)
     const uint64_t *luts;       // leaf level: [n_sets][inst_per_input][lut_words]; else null
     const uint64_t *in;         // inner levels: GLWE [instances][2 * nodes_out][K1][512]
     uint64_t *out;              // GLWE [instances][nodes_out][K1][512]
@@ -413,17 +421,14 @@ __global__ __launch_bounds__(EP_THREADS, 2) void cmux_level_kernel(const CmuxArg
 {
     static_assert(R * K1 <= EP_GROUPS, "too many polynomials for 16 lane groups");
     __shared__ __attribute__((aligned(16))) double lds[EP_LDS_DOUBLES];
-    double2 *psi = reinterpret_cast<double2 *>(lds + EP_GROUPS * GROUP_TILE_DOUBLES);
-    double2 *tw = psi + FHE_H;
+    double2 *tw = reinterpret_cast<double2 *>(lds + EP_GROUPS * GROUP_TILE_DOUBLES);
     const int tid = threadIdx.x;
     const int g = tid >> 4, b = tid & 15;
     const bool owner = g < R * K1;
     const int r_own = owner ? g / K1 : R - 1;
     const int p_own = owner ? g % K1 : K1 - 1;
     double *tile = lds + g * GROUP_TILE_DOUBLES;
-    const FftConsts fc = A.fc;
-    psi[tid] = A.psi[tid];
-    tw[tid] = A.tw[tid];
+    ep_load_table(tw, A.tw);
 
     const uint64_t input = blockIdx.x / A.wg_per_input;
     const uint32_t jobs_per_input = A.inst_per_input * A.nodes_out;
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void cmux_level_kernel(const CmuxArg
         }
     }
     __syncthreads();   // tables visible
-    nega_fwd(xr, xi, psi, tw, tile, b, fc);
+    nega_fwd(xr, xi, tw, tile, b);
 #pragma unroll
     for (int k2 = 0; k2 < 16; ++k2) {
         double2 v; v.x = xr[k2]; v.y = xi[k2];
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(EP_THREADS, 2) void cmux_level_kernel(const CmuxArg
         xr[k2] = v.x; xi[k2] = v.y;
     }
     wave_lds_sync();
-    nega_inv(xr, xi, psi, tw, tile, b, fc);
+    nega_inv(xr, xi, tw, tile, b);
     if (valid) {
         uint64_t *o = A.out + ((inst * A.nodes_out + node) * K1 + p_own) * FHE_N;
 #pragma unroll
@@ -517,16 +522,13 @@ __global__ __launch_bounds__(EP_THREADS, 2) void cmux_level_kernel(const CmuxArg
 }
 
 // K4: `polys` torus polynomials (natural u64[512]) -> Fourier double2[256], one polynomial per lane group
-__global__ __launch_bounds__(EP_THREADS) void forward_fourier_kernel(const uint64_t *in, double2 *out, uint64_t polys,
-                                                                     const double2 *psi_g, const double2 *tw_g, FftConsts fc)
+__global__ __launch_bounds__(EP_THREADS) void forward_fourier_kernel(const uint64_t *in, double2 *out, uint64_t polys, const double2 *tw_g)
 {
     __shared__ __attribute__((aligned(16))) double lds[EP_LDS_DOUBLES];
-    double2 *psi = reinterpret_cast<double2 *>(lds + EP_GROUPS * GROUP_TILE_DOUBLES);
-    double2 *tw = psi + FHE_H;
+    double2 *tw = reinterpret_cast<double2 *>(lds + EP_GROUPS * GROUP_TILE_DOUBLES);
     const int tid = threadIdx.x, g = tid >> 4, b = tid & 15;
     double *tile = lds + g * GROUP_TILE_DOUBLES;
-    psi[tid] = psi_g[tid];
-    tw[tid] = tw_g[tid];
+    ep_load_table(tw, tw_g);
     __syncthreads();
     for (uint64_t base = (uint64_t)blockIdx.x * EP_GROUPS; base < polys; base += (uint64_t)gridDim.x * EP_GROUPS) {
         uint64_t q = base + g;
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(EP_THREADS) void forward_fourier_kernel(const uint6
             xr[a] = double_from_torus(p[16 * a + b]);
             xi[a] = double_from_torus(p[256 + 16 * a + b]);
         }
-        nega_fwd(xr, xi, psi, tw, tile, b, fc);
+        nega_fwd(xr, xi, tw, tile, b);
         if (valid) {
             double2 *o = out + q * FHE_H;
 #pragma unroll

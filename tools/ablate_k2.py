@@ -17,6 +17,46 @@ from tfhe_aes_amd.client import Client  # noqa: E402
 
 VARIANTS = {
     "base": [],
+    "pk17_2": ["-DBR16_PARK_AUX_ST=17", "-DBR16_PARK_AUX_LD=2"],
+    "pk16_2": ["-DBR16_PARK_AUX_ST=16", "-DBR16_PARK_AUX_LD=2"],
+    "pk17_18": ["-DBR16_PARK_AUX_ST=17", "-DBR16_PARK_AUX_LD=18"],
+    "pk17_0": ["-DBR16_PARK_AUX_ST=17", "-DBR16_PARK_AUX_LD=0"],
+
+    "pk2_2": ["-DBR16_PARK_AUX_ST=2", "-DBR16_PARK_AUX_LD=2"],
+    "pk16_16": ["-DBR16_PARK_AUX_ST=16", "-DBR16_PARK_AUX_LD=16"],
+    "pk17_17": ["-DBR16_PARK_AUX_ST=17", "-DBR16_PARK_AUX_LD=17"],
+    "pk18_18": ["-DBR16_PARK_AUX_ST=18", "-DBR16_PARK_AUX_LD=18"],
+    "pk19_19": ["-DBR16_PARK_AUX_ST=19", "-DBR16_PARK_AUX_LD=19"],
+    "pk2_0": ["-DBR16_PARK_AUX_ST=2", "-DBR16_PARK_AUX_LD=0"],
+    "pk0_2": ["-DBR16_PARK_AUX_ST=0", "-DBR16_PARK_AUX_LD=2"],
+    "pk16_0": ["-DBR16_PARK_AUX_ST=16", "-DBR16_PARK_AUX_LD=0"],
+    "pk0_16": ["-DBR16_PARK_AUX_ST=0", "-DBR16_PARK_AUX_LD=16"],
+    "pk18_0": ["-DBR16_PARK_AUX_ST=18", "-DBR16_PARK_AUX_LD=0"],
+    "pk3_3": ["-DBR16_PARK_AUX_ST=3", "-DBR16_PARK_AUX_LD=3"],
+    "pk1_1": ["-DBR16_PARK_AUX_ST=1", "-DBR16_PARK_AUX_LD=1"],
+
+    "fall": ["-DEP_FENCE_MASK=0xFFF"],
+    "f0": ["-DEP_FENCE_MASK=1"],
+    "f1": ["-DEP_FENCE_MASK=2"],
+    "f2": ["-DEP_FENCE_MASK=4"],
+    "f3": ["-DEP_FENCE_MASK=8"],
+    "f4": ["-DEP_FENCE_MASK=16"],
+    "f5": ["-DEP_FENCE_MASK=32"],
+    "f6": ["-DEP_FENCE_MASK=64"],
+    "f7": ["-DEP_FENCE_MASK=128"],
+    "f8": ["-DEP_FENCE_MASK=256"],
+    "f9": ["-DEP_FENCE_MASK=512"],
+    "f10": ["-DEP_FENCE_MASK=1024"],
+    "f11": ["-DEP_FENCE_MASK=2048"],
+
+    "nochunk": ["-DFFT_CHUNK_BARRIERS=0"],
+    "chunk2": ["-DFFT_CHUNK=2"], "chunk8": ["-DFFT_CHUNK=8"], "chunk1nb": ["-DFFT_CHUNK=1", "-DFFT_CHUNK_BARRIERS=0"], "chunk1": ["-DFFT_CHUNK=1"],
+    "chunk4_e17": ["-DBR16_EARLY=17"], "chunk2_e17": ["-DFFT_CHUNK=2", "-DBR16_EARLY=17"],
+    "notwist": ["-DBR16_ABL_NOTWIST"],
+    "oldint": ["-DFHE_PEEL_OLD", "-DFHE_TORUS_CONV_OLD"],
+    "oldpeel": ["-DFHE_PEEL_OLD"],
+    "oldconv": ["-DFHE_TORUS_CONV_OLD"],
+    "e17": ["-DBR16_EARLY=17"],
     "stamps": ["-DEP_STAMPS"],
     "old16": ["-DPBS_FORM16=0"],
     "form32": ["-DPBS_FORM32=1"],
@@ -31,7 +71,6 @@ VARIANTS = {
     "nobal": ["-DPBS_BALANCE=0"], "nor2": ["-DPBS_SMALL_R2=0"],
     "aux1": ["-DEP_KEY_AUX=1"], "aux2": ["-DEP_KEY_AUX=2"], "aux16": ["-DEP_KEY_AUX=16"], "aux17": ["-DEP_KEY_AUX=17"],
     "aux18": ["-DEP_KEY_AUX=18"], "aux3": ["-DEP_KEY_AUX=3"], "aux19": ["-DEP_KEY_AUX=19"],
-    "parknt": ["-DBR16_PARK_NT=1"], "parknt_aux2": ["-DBR16_PARK_NT=1", "-DEP_KEY_AUX=2"],
     "stag8_1": ["-DBR16_STAGGER_SHIFT=8", "-DBR16_STAGGER_SLEEP=1"],
     "stag8_2": ["-DBR16_STAGGER_SHIFT=8", "-DBR16_STAGGER_SLEEP=2"],
     "stag8_4": ["-DBR16_STAGGER_SHIFT=8", "-DBR16_STAGGER_SLEEP=4"],

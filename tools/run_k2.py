@@ -1,5 +1,5 @@
 """Developer tool: run the blind-rotation stage (K2) alone on M resident bits, for rocprofv3 counter passes.
-usage: python3 tools/run_k2.py [M] [launches]"""
+usage: python3 tools/run_k2.py [M] [launches] [developer build of libfheaes.so to profile instead of the product's]"""
 import sys
 import time
 from pathlib import Path
@@ -12,6 +12,9 @@ import torch  # noqa: E402
 from tfhe_aes_amd import PARAM_OPT, _native  # noqa: E402
 from tfhe_aes_amd.client import Client  # noqa: E402
 
+if len(sys.argv) > 3:                      # a variant built by tools/ablate_k2.py (gpurun_out/abl/*.so)
+    _alt = Path(sys.argv[3]).resolve()
+    _native._build.build_engine = lambda *a, **k: _alt
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 p = PARAM_OPT
