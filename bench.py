@@ -170,6 +170,9 @@ def main():
         dist.all_reduce(probe)                      # the first collective creates the communicator
         torch.cuda.synchronize()
         rccl1 = {"init_and_first_all_reduce_s": round(time.time() - t0, 3), "ranks": 1}
+        # marker for tests/test_gpu_bench_dist.py: past this line a communicator EXISTS, so any later RCCL error is a
+        # failure of this code, not of the box
+        print("RCCL_COMMUNICATOR_READY", file=sys.stderr, flush=True)
 
     # ---- keys: generated on rank 0, broadcast once over RCCL/xGMI --------------------------------
     client = Client(args.blocks * world, IV, KEY, params=p, seed=0xAE50001)     # secret keys: same seed on every rank
@@ -303,6 +306,39 @@ def main():
                             "then Server::aes_encrypt; the timed `value` uses client-side pre-incremented counters" % n_blocks}
         del st2
 
+    # ---- BASELINE configs[4] shard: Server::aes_decrypt on 32 blocks (256 blocks / 8 GPUs), one extra verified step ------------
+    dec32 = None
+    if rank == 0 and world == 1 and not args.ctr_add and not args.decrypt and not args.no_ctr_iteration and n_blocks >= 32 and not args.no_verify:
+        st4 = state[:32].clone()
+        eng.aes_decrypt(rk, st4, 32)                      # warm-up (workspace growth for the 4-LUT packing)
+        eng.synchronize()                                 # the engine has its own stream: finish before torch overwrites st4
+        st4.copy_(state[:32])
+        torch.cuda.synchronize()
+        eng.profile_enable(True)
+        eng.profile_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.aes_decrypt(rk, st4, 32)
+        eng.synchronize()
+        dt = time.perf_counter() - t0
+        pr4 = eng.profile_read()
+        eng.profile_enable(False)
+        ok = True
+        for i in (0, 15, 31):
+            want = counters[i]
+            for _ in range(args.warmup + args.steps - 1):
+                want = aes128_encrypt_block(KEY, want)
+            ok = ok and client.decrypt_u128(st4[i].cpu().numpy().view(np.uint64)) == want
+        b4 = pr4["blind_rotate"]
+        l4 = max(1, b4["launches"])
+        k2_ms = b4["ms"] / l4
+        f4 = (b4["units"] / l4) * p.n * ext_product_flops(p) / (k2_ms * 1e-3) / 1e12 if k2_ms > 0 else 0.0
+        dec32 = {"blocks_per_s": 32 / dt, "ms": 1000.0 * dt, "verified_vs_aes": bool(ok), "k2_launches": l4, "k2_bits_per_launch": b4["units"] / l4,
+                 "k2_ms_per_launch": k2_ms, "k2_frac_of_f64_valu_peak": f4 / F64_VALU_PEAK_TFLOPS,
+                 "note": "BASELINE configs[4] per-GPU shard (256 blocks / 8 GPUs): Server::aes_decrypt on 32 resident blocks, 2,432 bit-CBS per block "
+                         "(inverse S-Box + 4-LUT inverse MixColumns packing, server.rs:67-105); one step, every launch is 4,096 bits"}
+        del st4
+
     # ---- BASELINE configs[1]: one AES block = 16 S-Box WoPBS in one call (latency, not throughput) ------------
     one_block_ms = None
     if rank == 0:
@@ -334,13 +370,14 @@ def main():
         tflops = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         # measured HBM-side bytes per launch: only from a PMC summary taken from these very engine sources
         from tfhe_aes_amd import _build
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu_busy, ceiling_frac, pmc_clock = None, None, None, None, None
         for pmc in sorted((ROOT / "profiles").glob("*pmc_blind_rotate*.json")):
             try:
                 d = json.loads(pmc.read_text())
                 if (d.get("engine_src_sha256") == _build.engine_source_hash() and d.get("bits_per_launch") == bits_per_launch
                         and d.get("params") == p.name):
                     traffic, traffic_src = d.get("hbm_bytes_per_launch"), pmc.name
+                    valu_busy, ceiling_frac, pmc_clock = d.get("valu_busy"), d.get("ceiling_frac"), d.get("effective_clock_ghz")
             except Exception:
                 pass
         stage_ms = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
@@ -362,11 +399,17 @@ def main():
             "config1_one_block_round": {"many_sbox_16_bytes_ms": one_block_ms, "ms_per_sbox": None if one_block_ms is None else one_block_ms / 16.0,
                                         "note": "BASELINE configs[1]: 16 S-Box WoPBS (128 bit-CBS) in one call: latency of the 669-step rotation chain"},
             "ctr_iteration_with_add_scalar": ctr_iter,
+            "configs4_decrypt_32_blocks": dec32,
             "stage_ms_per_step": stage_ms,
             "roofline": {
                 "kernel": "blind_rotate16_kernel (blind rotation, K2)", "bound": "valu_f64",
                 "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_VALU_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "bits_per_launch": bits_per_launch,
+                # from the same source-stamped counter file (null without one): the fraction of the roof this kernel's instruction
+                # stream would reach if a vector instruction issued on every SIMD cycle at the nominal 2.4 GHz (ISA count x
+                # per-instruction issue cost, tools/k2_dyncount.py), the measured share of SIMD cycles with a vector instruction
+                # issuing (SQ_ACTIVE_INST_VALU), and the clock the chip held under this kernel: frac ~ ceiling x busy x clock / 2.4
+                "ceiling_frac": ceiling_frac, "valu_busy": valu_busy, "clock_ghz": pmc_clock,
                 "algorithmic_flops_per_launch": flops, "flops_per_external_product": ext_product_flops(p),
                 "note": "at 16,384 bits per launch the kernel is bound by f64 vector issue (+ LDS and L1 fill time that do not overlap it), "
                         "not by HBM: the BSK is read once per launch",

@@ -62,7 +62,8 @@ typedef struct fheaes_ctx fheaes_ctx;
 /* Server::new (server.rs:32): create an engine on HIP device `device`. */
 int fheaes_create(const fheaes_params *params, int device, fheaes_ctx **out);
 void fheaes_destroy(fheaes_ctx *ctx);
-/* message of the last failing call on this context (ctx == NULL: last fheaes_create failure) */
+/* message of the last failing call on this context (ctx == NULL: last fheaes_create failure).  The pointer is a per-thread copy,
+ * valid until the same thread's next call into the library (a context may be shared between threads). */
 const char *fheaes_last_error(const fheaes_ctx *ctx);
 
 /* ---- keys ---------------------------------------------------------------------- */
@@ -88,6 +89,14 @@ size_t fheaes_key_body_words(const fheaes_ctx *ctx, int which);
 int fheaes_upload_keys_seeded(fheaes_ctx *ctx, const uint32_t *mask_key, const uint64_t *ksk_body, const uint64_t *bsk_body,
                               const uint64_t *pfpksk_body, int memspace);
 
+/* Several engines, one upload.  The reference is ONE process that fans the CTR blocks out over rayon worker threads which share
+ * `&Server` (main.rs:55-64, server.rs:32-35): a drop-in that wants G GPUs (or several concurrent streams on one GPU) creates G
+ * contexts, uploads the keys into the first and clones the CONVERTED key images (1.04 GB) into the others, device to device:
+ * hipMemcpyPeerAsync over xGMI between GPUs, an HBM copy inside one.  Block i then goes to context i * G / n_blocks, one host
+ * thread per context (contexts are independent: own stream, own workspace; calls on ONE context are serialised by its lock).
+ * Both contexts must have been created with the same parameter set. */
+int fheaes_clone_keys(fheaes_ctx *dst, fheaes_ctx *src);
+
 /* ---- stream / sync / workspace ------------------------------------------------- */
 int fheaes_set_stream(fheaes_ctx *ctx, void *hip_stream); /* NULL: the context's own stream */
 int fheaes_synchronize(fheaes_ctx *ctx);
@@ -111,7 +120,9 @@ int fheaes_forward_fourier_batch(fheaes_ctx *ctx, const uint64_t *polys_in, uint
  *     luts [n_sets][n_luts][bits][W] with n_sets = lut_per_input ? n_inputs : 1 and W = max(2^bits, N) words per
  *     (LUT, output bit) as gen_lut.rs:19-23 sizes them; out [n_inputs][n_luts][bits][kN+1].
  *     bits <= 9 (all the AES path uses): one LUT polynomial per output bit, blind rotation only.  9 < bits <= 16: the
- *     2^(bits-9) polynomials go through the CMUX tree over input bits 9..bits-1 first, then the rotation over bits 0..8. */
+ *     2^(bits-9) polynomials go through the CMUX tree over input bits 9..bits-1 first, then the rotation over bits 0..8
+ *     ("parity unpinned" for bits > 9: the reference never calls many_wopbs_without_padding wider than 9 bits and holds no
+ *     fixture for it; the split follows upstream vertical_packing and is checked against this repo's oracle only). */
 int fheaes_vertical_packing_batch(fheaes_ctx *ctx, const double *ggsw_fourier, uint64_t n_inputs, uint32_t bits,
                                   const uint64_t *luts, uint32_t n_luts, int lut_per_input, uint64_t *lwe_out, int memspace);
 

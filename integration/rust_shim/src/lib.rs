@@ -14,6 +14,10 @@
 //!   GpuServer::aes_encrypt                 Server::aes_encrypt             src/server/server.rs:39   (batched over CTR blocks)
 //!   GpuServer::aes_decrypt                 Server::aes_decrypt             src/server/server.rs:67   (batched)
 //!   GpuServer::add_scalar                  Server::add_scalar              src/server/server.rs:172  (batched; carry defect of :182 fixed)
+//!   GpuServer::clone_on                    (Server is shared by reference between rayon threads, main.rs:55-64; a GPU context
+//!                                           is cloned instead: one PCIe key upload, device-to-device copies, fheaes_clone_keys)
+//!   GpuServerGroup::{new, aes_encrypt, aes_decrypt, add_scalar}
+//!                                          the rayon loop over CTR blocks of src/main.rs:55-64, one context per GPU
 //!   fourier_bsk_to_standard                (no counterpart: the reference only holds the Fourier BSK, many_wopbs.rs:34-35)
 #![allow(non_camel_case_types)]
 
@@ -30,6 +34,7 @@ use tfhe::shortint::{Ciphertext, WopbsParameters};
 
 // ------------------------------------------------------------------------------------------------ FFI
 #[repr(C)]
+#[derive(Clone, Copy)]
 pub struct fheaes_params {
     pub lwe_dimension: u32,
     pub glwe_dimension: u32,
@@ -54,6 +59,8 @@ extern "C" {
     pub fn fheaes_destroy(ctx: *mut fheaes_ctx);
     pub fn fheaes_last_error(ctx: *const fheaes_ctx) -> *const c_char;
     pub fn fheaes_upload_keys(ctx: *mut fheaes_ctx, ksk: *const u64, bsk: *const u64, pfpksk: *const u64, memspace: c_int) -> c_int;
+    pub fn fheaes_clone_keys(dst: *mut fheaes_ctx, src: *mut fheaes_ctx) -> c_int;
+    pub fn fheaes_synchronize(ctx: *mut fheaes_ctx) -> c_int;
     pub fn fheaes_wopbs_batch(ctx: *mut fheaes_ctx, lwe_in: *const u64, n_inputs: u64, bits: u32, luts: *const u64,
                               n_luts: u32, lut_per_input: c_int, lwe_out: *mut u64, memspace: c_int) -> c_int;
     pub fn fheaes_sbox(ctx: *mut fheaes_ctx, bytes: *mut u64, n_bytes: u64, inv: c_int, memspace: c_int) -> c_int;
@@ -169,8 +176,13 @@ pub fn fourier_bsk_to_standard(fbsk: &FourierLweBootstrapKeyOwned, level_most_si
 // ------------------------------------------------------------------------------------------------ GpuServer
 pub struct GpuServer {
     ctx: *mut fheaes_ctx,
+    params: fheaes_params,
 }
+// one context = one HIP stream + one workspace; the engine serialises calls on a context (its own lock), so `&GpuServer` may
+// be shared between threads exactly like the reference's `&Server` (main.rs:55-61) -- safe, but serialised: use one context
+// per thread (GpuServerGroup) for concurrency
 unsafe impl Send for GpuServer {}
+unsafe impl Sync for GpuServer {}
 
 impl GpuServer {
     /// Server::new (server.rs:32) from the reference's own key object alone: the Fourier BSK is taken back to the standard
@@ -213,9 +225,27 @@ impl GpuServer {
         let glwe_words = (p.glwe_dimension.0 + 1) * p.polynomial_size.0;
         let pf_flat = reverse_levels(wopbs_key_short.cbs_pfpksk.as_ref(), p.pfks_level.0, glwe_words); // many_wopbs.rs:76
         let rc = unsafe { fheaes_upload_keys(ctx, ksk_flat.as_ptr(), std_bsk.as_ref().as_ptr(), pf_flat.as_ptr(), FHEAES_HOST) };
-        let s = GpuServer { ctx };
+        let s = GpuServer { ctx, params };
         assert!(rc == 0, "fheaes_upload_keys: {}", s.last_error());
         s
+    }
+
+    /// A second engine with the SAME keys on HIP device `device` (the same GPU or another one): the converted key images
+    /// (1.04 GB) are copied device to device -- hipMemcpyPeerAsync over xGMI between GPUs -- instead of being uploaded
+    /// and converted again.  Replaces sharing `&Server` between rayon workers (main.rs:55-64, server.rs:32-35).
+    pub fn clone_on(&self, device: i32) -> Self {
+        let mut ctx = std::ptr::null_mut();
+        let rc = unsafe { fheaes_create(&self.params, device, &mut ctx) };
+        assert!(rc == 0, "fheaes_create failed: {}", last_error(std::ptr::null()));
+        let s = GpuServer { ctx, params: self.params };
+        let rc = unsafe { fheaes_clone_keys(s.ctx, self.ctx) };
+        assert!(rc == 0, "fheaes_clone_keys: {}", s.last_error());
+        s
+    }
+
+    pub fn synchronize(&self) {
+        let rc = unsafe { fheaes_synchronize(self.ctx) };
+        assert!(rc == 0, "{}", self.last_error());
     }
 
     pub fn last_error(&self) -> String {
@@ -349,6 +379,79 @@ impl GpuServer {
         for (s, words) in states.iter_mut().zip(st.chunks_exact(state_words)) {
             rewrap_state(words, s);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GpuServerGroup
+/// The reference's CTR loop (src/main.rs:55-64) runs blocks in parallel with rayon over ONE `&Server`.  On GPUs the unit of
+/// parallelism is a context: `GpuServerGroup` holds one `GpuServer` per device (keys uploaded once, cloned device to device),
+/// gives block i to context i * G / n_blocks (contiguous shards, no data moves between contexts) and drives every context
+/// from its own host thread.  (bench.py reaches the same split with one PROCESS per GPU and an RCCL broadcast of the seeded
+/// keys; this is the in-process form a drop-in for the reference needs.)
+pub struct GpuServerGroup {
+    servers: Vec<GpuServer>,
+}
+
+impl GpuServerGroup {
+    pub fn new(wopbs_key_short: &tfhe::shortint::wopbs::WopbsKey, std_bsk: &LweBootstrapKeyOwned<u64>, devices: &[i32]) -> Self {
+        assert!(!devices.is_empty());
+        let first = GpuServer::new(wopbs_key_short, std_bsk, devices[0]);
+        let mut servers = Vec::with_capacity(devices.len());
+        for &d in &devices[1..] {
+            servers.push(first.clone_on(d));
+        }
+        servers.insert(0, first);
+        GpuServerGroup { servers }
+    }
+
+    /// [start, end) of the blocks of context `i` (the same rule as tfhe_aes_amd/dist.py::shard_blocks)
+    fn shard(n: usize, g: usize, i: usize) -> (usize, usize) {
+        let (base, rem) = (n / g, n % g);
+        let start = i * base + i.min(rem);
+        (start, start + base + usize::from(i < rem))
+    }
+
+    fn fan_out<F>(&self, states: &mut [Vec<Radix>], f: F)
+    where
+        F: Fn(&GpuServer, &mut [Vec<Radix>], usize) + Sync,
+    {
+        let g = self.servers.len();
+        let n = states.len();
+        std::thread::scope(|scope| {
+            let mut rest = states;
+            for (i, srv) in self.servers.iter().enumerate() {
+                let (lo, hi) = Self::shard(n, g, i);
+                let (mine, tail) = rest.split_at_mut(hi - lo);
+                rest = tail;
+                let f = &f;
+                scope.spawn(move || {
+                    if !mine.is_empty() {
+                        f(srv, mine, lo);
+                    }
+                });
+            }
+        });
+    }
+
+    /// Server::aes_encrypt (server.rs:39) over all CTR blocks, sharded over the contexts
+    pub fn aes_encrypt(&self, round_keys: &[Vec<Radix>], states: &mut [Vec<Radix>]) {
+        self.fan_out(states, |srv, shard, _| srv.aes_encrypt(round_keys, shard));
+    }
+
+    /// Server::aes_decrypt (server.rs:67)
+    pub fn aes_decrypt(&self, round_keys: &[Vec<Radix>], states: &mut [Vec<Radix>]) {
+        self.fan_out(states, |srv, shard, _| srv.aes_decrypt(round_keys, shard));
+    }
+
+    /// Server::add_scalar (server.rs:172): states[b] += counters[b]
+    pub fn add_scalar(&self, states: &mut [Vec<Radix>], counters: &[u128]) {
+        assert_eq!(states.len(), counters.len());
+        self.fan_out(states, |srv, shard, lo| srv.add_scalar(shard, &counters[lo..lo + shard.len()]));
+    }
+
+    /// Server::aes_key_expansion (server.rs:107): a latency chain of 50 dependent steps, one context
+    pub fn aes_key_expansion(&self, key: &[Radix]) -> Vec<Vec<Radix>> {
+        self.servers[0].aes_key_expansion(key)
     }
 }
 

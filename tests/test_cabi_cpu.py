@@ -96,3 +96,21 @@ def test_k2_launch_plan_covers_the_batch_in_whole_generations():
     for bad in ((0, 256), (16, 0)):
         f = C.c_int(); a = C.c_uint64(); b = C.c_uint32(); c = C.c_uint64(); d = C.c_uint32()
         assert lib.fheaes_k2_launch_plan(bad[0], bad[1], 4, C.byref(f), C.byref(a), C.byref(b), C.byref(c), C.byref(d)) != 0
+
+
+def test_fft_constants_header_matches_the_twiddle_table():
+    """csrc/fft_consts.h (generated by tools/gen_fft_consts.py) holds the lane-independent twiddles of the kernels' transform as
+    literals: psi^(16 m), m < 32.  They must BE the table both sides derive from the same specification -- the engine's host
+    table (fheaes_get_twiddles) and the oracle's -- bit for bit; fheaes_create checks the same at run time."""
+    import re
+
+    from oracle import oracle as orc
+
+    text = (_build.CSRC / "fft_consts.h").read_text()
+    arrays = {}
+    for name, body in re.findall(r"static constexpr double (\w+)\[32\] = \{(.*?)\};", text, flags=re.S):
+        arrays[name] = [float.fromhex(x.strip()) for x in body.split(",") if x.strip()]
+    assert sorted(arrays) == ["FHE_PSI16_IM", "FHE_PSI16_RE"] and all(len(v) == 32 for v in arrays.values())
+    for t in (_native.get_twiddles(), orc.twiddles()):
+        assert np.array_equal(np.array(arrays["FHE_PSI16_RE"]).view(np.uint64), np.ascontiguousarray(t[::16, 0][:32]).view(np.uint64))
+        assert np.array_equal(np.array(arrays["FHE_PSI16_IM"]).view(np.uint64), np.ascontiguousarray(t[::16, 1][:32]).view(np.uint64))

@@ -58,9 +58,15 @@ def test_bench_one_rank_through_rccl():
         env.pop(k, None)
     res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--params", "toy", "--blocks", "2", "--steps", "1", "--warmup", "0",
                           "--rccl-one-rank", "--no-cpu-baseline", "--no-ctr-iteration"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
-    if res.returncode != 0 and any(k in res.stderr for k in ("ncclSystemError", "ncclUnhandledCudaError", "ncclInternalError", "NCCL error")):
-        pytest.skip("RCCL could not create a communicator on this box: " + res.stderr.strip().splitlines()[-1][:300])
-    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    # The only acceptable skip: RCCL could not CREATE a communicator on this box (bench.py prints RCCL_COMMUNICATOR_READY to stderr
+    # once init_process_group and the probe all-reduce have succeeded).  The skip reason carries the whole stderr tail.  Any error
+    # after the marker -- the seeded-key broadcasts, the elapsed-time all-reduce, destroy_process_group -- fails the test.
+    # (Seen once, on one box of the pool in round 2: ncclSystemError from communicator creation)
+    created = "RCCL_COMMUNICATOR_READY" in res.stderr
+    if res.returncode != 0 and not created and any(k in res.stderr for k in ("ncclSystemError", "ncclUnhandledCudaError", "ncclInternalError", "NCCL error")):
+        pytest.skip("RCCL could not create a communicator on this box (no collective ran); stderr tail:\n" + res.stderr[-3000:])
+    assert res.returncode == 0, ("RCCL communicator was created, then: " if created else "") + res.stdout[-2000:] + res.stderr[-4000:]
+    assert created
     line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
     r = line["rccl_one_rank"]
     assert r["ranks"] == 1 and r["key_broadcast_intact"] is True and r["elapsed_all_reduce_max_ok"] is True

@@ -26,8 +26,9 @@ def test_twiddles_and_bsk_fourier(which, request):
         assert np.array_equal(E.read_bsk_fourier(i).view(np.uint64), orc.polys_to_fourier(bsk[i]).view(np.uint64))
 
 
-@pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 33), ("toy", 100), ("opt", 1), ("opt", 35)])
+@pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 33), ("toy", 100), ("opt", 1), ("opt", 35), ("opt", 200)])
 def test_k1_keyswitch(which, m, request):
+    # opt 200: four 64-ciphertext tiles (grid.y = 4), ragged last one, every word against the oracle
     kit = request.getfixturevalue(which)
     p, E = kit.params, kit.engine()
     x, _ = _inputs(kit, m, 10 + m)
@@ -56,8 +57,10 @@ def test_k2_blind_rotation(which, m, request):
     assert np.abs(ph.astype(np.int64) - bits.astype(np.int64) * delta).max() < delta // 8
 
 
-@pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 40), ("opt", 3), ("opt", 33)])
+@pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 40), ("toy", 300), ("opt", 3), ("opt", 33), ("opt", 300)])
 def test_k3_pfpks(which, m, request):
+    # the LDS-tiled kernel owns 128 ciphertexts per workgroup: 300 = three tiles (grid.y = 3), ragged last one, with the k = 4
+    # column tiling (2,560 columns, out_z_stride) -- every word against the oracle (~80 M multiply-adds per bit on the CPU)
     kit = request.getfixturevalue(which)
     p, E = kit.params, kit.engine()
     rng = np.random.default_rng(30 + m)

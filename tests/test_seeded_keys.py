@@ -59,6 +59,14 @@ def test_compress_expand_roundtrip_and_sizes(toy, tmp_path):
     assert np.array_equal(back.mask_seed, sk.mask_seed) and np.array_equal(back.bsk_body, sk.bsk_body)
     with pytest.raises(ValueError):
         ServerKeys(p, keys.ksk, keys.bsk, keys.pfpksk).compress()         # foreign keys carry no mask seed
+    # FULL keys through a file keep their public mask seed: save -> load -> compress -> expand is the identity
+    keys.save(tmp_path / "full.npz")
+    again = ServerKeys.load(tmp_path / "full.npz", p)
+    assert again.mask_seed is not None and again.mask_seed.dtype == np.uint32 and np.array_equal(again.mask_seed, keys.mask_seed)
+    full2 = again.compress().expand()
+    assert np.array_equal(full2.ksk, keys.ksk) and np.array_equal(full2.bsk, keys.bsk) and np.array_equal(full2.pfpksk, keys.pfpksk)
+    ServerKeys(p, keys.ksk, keys.bsk, keys.pfpksk).save(tmp_path / "foreign.npz")      # and foreign keys stay seedless
+    assert ServerKeys.load(tmp_path / "foreign.npz", p).mask_seed is None
 
 
 def test_compression_ratio_param_opt():

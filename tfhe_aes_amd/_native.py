@@ -31,6 +31,7 @@ SIGNATURES = {
     "fheaes_upload_keys": (_c.c_int, [_ctx, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int]),
     "fheaes_key_body_words": (_c.c_size_t, [_ctx, _c.c_int]),
     "fheaes_upload_keys_seeded": (_c.c_int, [_ctx, _c.POINTER(_c.c_uint32), _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int]),
+    "fheaes_clone_keys": (_c.c_int, [_ctx, _ctx]),
     "fheaes_set_stream": (_c.c_int, [_ctx, _c.c_void_p]),
     "fheaes_synchronize": (_c.c_int, [_ctx]),
     "fheaes_reserve": (_c.c_int, [_ctx, _c.c_uint64]),
@@ -166,6 +167,11 @@ class Engine:
                 raise ValueError("key body %d has %d words, expected %d" % (which, n, self._lib.fheaes_key_body_words(self._h, which)))
         self._check(self._lib.fheaes_upload_keys_seeded(self._h, mk.ctypes.data_as(_c.POINTER(_c.c_uint32)), _ptr(ksk_body)[0], _ptr(bsk_body)[0],
                                                         _ptr(pfpksk_body)[0], sp))
+
+    def clone_keys_from(self, other: "Engine"):
+        """device-to-device copy of `other`'s converted key images into this context (fheaes_clone_keys): one PCIe upload serves
+        several contexts -- on other GPUs (over xGMI) or on the same one (independent streams and workspaces)"""
+        self._check(self._lib.fheaes_clone_keys(self._h, other._h))
 
     def set_stream(self, stream_handle: int | None):
         self._check(self._lib.fheaes_set_stream(self._h, stream_handle))

@@ -196,7 +196,8 @@ class ServerKeys:
     # The reference never serialises anything; these two helpers exist so that keys produced
     # elsewhere can be fed to the engine.  Plain .npz of uint64 arrays (no pickle), layouts as in include/fheaes.h.
     def save(self, path) -> None:
-        np.savez(path, shape=_param_shape(self.params), ksk=self.ksk, bsk=self.bsk, pfpksk=self.pfpksk)
+        extra = {} if self.mask_seed is None else {"mask_seed": np.asarray(self.mask_seed, dtype=np.uint32).reshape(8)}
+        np.savez(path, shape=_param_shape(self.params), ksk=self.ksk, bsk=self.bsk, pfpksk=self.pfpksk, **extra)
 
     @staticmethod
     def load(path, params: WopbsParameters) -> "ServerKeys":
@@ -205,7 +206,13 @@ class ServerKeys:
                     params.ks_base_log, params.ks_level, params.pfks_base_log, params.pfks_level, params.cbs_base_log, params.cbs_level]
             if list(map(int, z["shape"])) != want:
                 raise ValueError("key file was generated for a different parameter set")
-            keys = ServerKeys(params, z["ksk"].astype(np.uint64), z["bsk"].astype(np.uint64), z["pfpksk"].astype(np.uint64))
+            seed = None
+            if "mask_seed" in z.files:          # the public mask key travels with the keys: compress() still works after a round trip
+                seed = z["mask_seed"]
+                if seed.shape != (8,) or seed.dtype != np.uint32:
+                    raise ValueError("key file has a malformed mask_seed (expected uint32[8])")
+                seed = seed.copy()
+            keys = ServerKeys(params, z["ksk"].astype(np.uint64), z["bsk"].astype(np.uint64), z["pfpksk"].astype(np.uint64), seed)
         if (keys.ksk.size, keys.bsk.size, keys.pfpksk.size) != (params.ksk_words, params.bsk_words, params.pfpksk_words):
             raise ValueError("key file has the wrong array sizes")
         return keys

@@ -19,12 +19,6 @@
 #include "kern_extprod.h"
 #include "kern_blindrot_latency.h"
 #include "kern_blindrot16.h"
-#ifndef PBS_FORM32
-#define PBS_FORM32 0            /* developer build: the 32-lane experiment under tools/experiments (measured slower) */
-#endif
-#if PBS_FORM32
-#include "../../tools/experiments/kern_blindrot32.h"
-#endif
 #include "kern_keyswitch.h"
 #include "kern_linear.h"
 
@@ -35,6 +29,11 @@
 namespace {
 
 std::string g_create_error;
+// fheaes_last_error(): a context may be shared between threads (every call takes its lock), so the message a caller reads must
+// not be one that another thread is overwriting.  fail() keeps a per-thread copy; the pointer fheaes_last_error returns is valid
+// until the same thread's next call into the library.
+thread_local std::string tl_error;
+thread_local const void *tl_error_ctx = nullptr;
 
 // ---------------------------------------------------------------------------------------------
 // host tables
@@ -201,6 +200,7 @@ struct fheaes_ctx {
     // keys
     int8_t *ksk_frag = nullptr, *pfpksk_frag = nullptr;      // balanced key bytes in MFMA B-fragment order
     uint32_t ks_ksteps = 0, ks_coltiles = 0, pf_ksteps = 0, pf_coltiles = 0;
+    size_t ksk_frag_bytes = 0, pfpksk_frag_bytes = 0, bskf_bytes = 0;
     double2 *bskf = nullptr;
     bool have_keys = false;
     // tables
@@ -231,6 +231,8 @@ struct fheaes_ctx {
         vsnprintf(buf, sizeof buf, fmt, ap);
         va_end(ap);
         err = buf;
+        tl_error = buf;
+        tl_error_ctx = this;
         return code;
     }
 };
@@ -468,26 +470,6 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         else hipLaunchKernelGGL((blind_rotate_latency_kernel<2, 5, 8>), dim3((unsigned)m), dim3(BL_THREADS), 0, c->stream, a);
         // (257..768 bits: the throughput form below with at most one workgroup per CU, 14.6 ms per launch; the round-1
         //  one-ciphertext-per-workgroup form of kern_extprod.h took 21.6 ms there and the latency form in two waves 16-18 ms)
-#if PBS_FORM32
-    } else if (c->k1 == 5 || c->k1 == 2) {
-        // throughput form: 32 lanes per polynomial, 4 waves per SIMD (kern_blindrot32.h)
-        const unsigned R32 = c->k1 == 5 ? 3 : 8;
-        const unsigned grid32 = (unsigned)((m + R32 - 1) / R32);
-        TRY(ensure(c, c->ws_park, (size_t)grid32 * 8 * BR32_THREADS * 16));
-        a.park = (uint64_t *)c->ws_park.p;
-#ifdef EP_STAMPS
-        static const char *names32[EP_NPH] = {"stage+rotate+decomp_first", "decomp_next", "twist+step A", "pre-trip barrier", "trip1+step B",
-                                              "trip2+step C+digit stores", "exchange barrier", "MAC", "products exchange", "inverse fft", "convert+add", "loop head"};
-        StampReport rep(c, (size_t)grid32 * 8, names32);
-        a.stamps = rep.d;
-#endif
-        if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate32_kernel<5, 5, 8, 3>), dim3(grid32), dim3(BR32_THREADS), 0, c->stream, a);
-        else hipLaunchKernelGGL((blind_rotate32_kernel<2, 5, 8, 8>), dim3(grid32), dim3(BR32_THREADS), 0, c->stream, a);
-#endif
-#ifndef PBS_FORM16
-#define PBS_FORM16 1
-#endif
-#if PBS_FORM16
     } else {
         // throughput form (kern_blindrot16.h): accumulator parked in HBM between uses, key rows prefetched across the transform
         const K2Plan pl = k2_plan(m, c->cu_count, c->k1);
@@ -506,42 +488,6 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate16_kernel<5, 5, 8, 3, 2>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((blind_rotate16_kernel<2, 5, 8, 8>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
     }
-#else
-    } else if (c->k1 == 5) {
-#ifndef PBS_R
-#define PBS_R 3
-#endif
-        constexpr int R = PBS_R;
-#ifdef EP_STAMPS
-        const unsigned grid_s = (unsigned)((m + R - 1) / R);
-        unsigned long long *st_d = nullptr;
-        (void)hipMalloc((void **)&st_d, (size_t)grid_s * 4 * EP_NPH * 8);
-        (void)hipMemsetAsync(st_d, 0, (size_t)grid_s * 4 * EP_NPH * 8, c->stream);
-        a.stamps = st_d;
-#endif
-        hipLaunchKernelGGL((extprod_rotate_kernel<5, 5, 8, R, false>), dim3((unsigned)((m + R - 1) / R)), dim3(EP_THREADS), 0, c->stream, a);
-#ifdef EP_STAMPS
-        {
-            std::vector<unsigned long long> h((size_t)grid_s * 4 * EP_NPH);
-            (void)hipMemcpyAsync(h.data(), st_d, h.size() * 8, hipMemcpyDeviceToHost, c->stream);
-            (void)hipStreamSynchronize(c->stream);
-            (void)hipFree(st_d);
-            static const char *names[EP_NPH] = {"rotate+decomp_first", "decomp_next", "fwd head", "pre-level barrier", "fwd tail (transpose+dft16)",
-                                                "digit stores+early loads", "exchange barrier", "MAC", "products exchange", "inverse fft", "convert+add", "loop head"};
-            double tot[EP_NPH] = {}, all = 0;
-            for (size_t w = 0; w < (size_t)grid_s * 4; ++w) for (int i = 0; i < EP_NPH; ++i) tot[i] += (double)h[w * EP_NPH + i];
-            for (int i = 0; i < EP_NPH; ++i) all += tot[i];
-            fprintf(stderr, "K2 phase cycles per wave per iteration (s_memtime ticks, avg over %u waves):\n", grid_s * 4);
-            for (int i = 0; i < EP_NPH; ++i)
-                fprintf(stderr, "  %-28s %9.0f  %5.1f %%\n", names[i], tot[i] / ((double)grid_s * 4 * c->n), 100.0 * tot[i] / all);
-            fprintf(stderr, "  %-28s %9.0f\n", "total", all / ((double)grid_s * 4 * c->n));
-        }
-#endif
-    } else {
-        constexpr int R = 8;
-        hipLaunchKernelGGL((extprod_rotate_kernel<2, 5, 8, R, false>), dim3((unsigned)((m + R - 1) / R)), dim3(EP_THREADS), 0, c->stream, a);
-    }
-#endif
     HIP_TRY(c, hipGetLastError());
     return FHEAES_OK;
 }
@@ -732,7 +678,16 @@ int fheaes_k2_launch_plan(uint64_t m, uint32_t cu_count, uint32_t k, int *form, 
 }
 const char *fheaes_version(void) { return FHEAES_VERSION_STR; }
 
-const char *fheaes_last_error(const fheaes_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *fheaes_last_error(const fheaes_ctx *ctx)
+{
+    if (!ctx) return g_create_error.c_str();
+    if (tl_error_ctx != ctx) {                   // this thread has not failed on ctx: hand out a private copy of the context's last message
+        CtxLock lock__(ctx);
+        tl_error = ctx->err;
+        tl_error_ctx = ctx;
+    }
+    return tl_error.c_str();
+}
 
 int fheaes_get_twiddles(double *psi_out)
 {
@@ -884,6 +839,7 @@ static int upload_keys_impl(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *
     if (!c->ksk_frag) HIP_TRY(c, hipMalloc((void **)&c->ksk_frag, frag1));
     if (!c->pfpksk_frag) HIP_TRY(c, hipMalloc((void **)&c->pfpksk_frag, frag3));
     if (!c->bskf) HIP_TRY(c, hipMalloc((void **)&c->bskf, bw * 8));
+    c->ksk_frag_bytes = frag1; c->pfpksk_frag_bytes = frag3; c->bskf_bytes = bw * 8;
     // stage the standard-domain words in HBM (largest key first), transform, free
     void *tmp = nullptr, *tmp_body = nullptr;
     const size_t tmp_words = std::max(std::max(kw, bw), pw);
@@ -965,6 +921,40 @@ int fheaes_upload_keys_seeded(fheaes_ctx *c, const uint32_t *mask_key, const uin
     MaskKey k;
     memcpy(k.k, mask_key, sizeof k.k);                       // the 32-byte key itself is always a HOST array
     return upload_keys_impl(c, ksk_body, bsk_body, pfpksk_body, memspace, true, k);
+}
+
+// One upload over PCIe, then device-to-device copies of the CONVERTED key images (int8 fragment planes of KSK / PFPKSK, Fourier
+// BSK: 1.04 GB) -- over xGMI when the contexts sit on different GPUs (hipMemcpyPeerAsync), inside HBM when they share one.
+int fheaes_clone_keys(fheaes_ctx *dst, fheaes_ctx *src)
+{
+    if (!dst || !src) return FHEAES_ERR_INVALID;
+    if (dst == src) return dst->fail(FHEAES_ERR_INVALID, "fheaes_clone_keys: source and destination are the same context");
+    // both locks, in address order (two threads cloning in opposite directions must not deadlock)
+    CtxLock l1(dst < src ? dst : src), l2(dst < src ? src : dst);
+    if (!src->have_keys) return dst->fail(FHEAES_ERR_NOKEYS, "fheaes_clone_keys: the source context has no keys");
+    if (memcmp(&dst->p, &src->p, sizeof(fheaes_params)) != 0) return dst->fail(FHEAES_ERR_INVALID, "fheaes_clone_keys: parameter sets differ");
+    HIP_TRY(dst, hipSetDevice(src->device));
+    HIP_TRY(dst, hipStreamSynchronize(src->stream));            // the source's conversions are complete
+    HIP_TRY(dst, hipSetDevice(dst->device));
+    dst->have_keys = false;
+    struct { void **d; const void *s; size_t bytes; size_t *have; } img[3] = {
+        {(void **)&dst->ksk_frag, src->ksk_frag, src->ksk_frag_bytes, &dst->ksk_frag_bytes},
+        {(void **)&dst->pfpksk_frag, src->pfpksk_frag, src->pfpksk_frag_bytes, &dst->pfpksk_frag_bytes},
+        {(void **)&dst->bskf, src->bskf, src->bskf_bytes, &dst->bskf_bytes}};
+    for (auto &g : img) {
+        if (*g.d && *g.have != g.bytes) { HIP_TRY(dst, hipStreamSynchronize(dst->stream)); HIP_TRY(dst, hipFree(*g.d)); *g.d = nullptr; }
+        if (!*g.d) {
+            hipError_t e = hipMalloc(g.d, g.bytes);
+            if (e != hipSuccess) { *g.d = nullptr; return dst->fail(FHEAES_ERR_NOMEM, "hipMalloc(%zu bytes): %s", g.bytes, hipGetErrorString(e)); }
+        }
+        *g.have = g.bytes;
+        if (dst->device == src->device) HIP_TRY(dst, hipMemcpyAsync(*g.d, g.s, g.bytes, hipMemcpyDeviceToDevice, dst->stream));
+        else HIP_TRY(dst, hipMemcpyPeerAsync(*g.d, dst->device, g.s, src->device, g.bytes, dst->stream));
+    }
+    HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+    dst->ks_ksteps = src->ks_ksteps; dst->ks_coltiles = src->ks_coltiles; dst->pf_ksteps = src->pf_ksteps; dst->pf_coltiles = src->pf_coltiles;
+    dst->have_keys = true;
+    return FHEAES_OK;
 }
 
 size_t fheaes_key_body_words(const fheaes_ctx *c, int which)

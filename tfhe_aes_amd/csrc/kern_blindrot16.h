@@ -1,27 +1,25 @@
 // kern_blindrot16.h -- K2, blind rotation of the circuit-bootstrap PBS + sample extract,
 // throughput form for large batches (the same arithmetic and lane mapping as extprod_rotate_kernel in
-// kern_extprod.h, which stays the form of K5 and of medium batches; bit-identical results).
+// kern_extprod.h, which stays the form of K5; bit-identical results).
 //
-// What differs from kern_extprod.h, and why (measured with per-phase s_memtime stamps, profiles/r02_*):
+// What differs from kern_extprod.h, and why (measured with per-phase s_memtime stamps and rocprofv3 counters, profiles/r02_*, r03_*):
 //  * the accumulator (64 VGPRs per lane) is dead weight between the rotation at the top of an iteration and the
-//    accumulate at its end; the compiler spilled it (252 B/lane of scratch, ~430 GB of HBM traffic per launch, and
-//    the reloads sat on the critical path).  Here it is PARKED explicitly: stored once per iteration with
-//    coalesced 16-byte stores into a per-workgroup slab, reloaded into registers that are free by then, a whole
-//    products exchange + inverse transform ahead of its use.
-//  * with only two waves per SIMD nothing hides an LDS round trip but the wave's own instruction stream, and the
-//    compiler (at its register limit) kept ONE twiddle read in flight: each of the 31 table reads of a transform
-//    exposed ~100 cycles -- the "forward head" phase ran 3.6x longer than its arithmetic.  The 64 registers that
-//    parking frees hold two 8-entry twiddle buffers; table reads are issued a whole batch (and a whole DFT16 or
-//    decomposition step) ahead of their use.  The transformed digits of the next multiply-accumulate row are read
-//    one row ahead the same way.
+//    accumulate at its end; it is PARKED: stored once per iteration with coalesced 16-byte buffer stores into a per-workgroup
+//    slab, reloaded (non-temporal: its last use) into registers that are free by then, a whole products exchange + inverse
+//    transform ahead of its use.  It is kept NEGATED, which turns the rotation's negate / select / subtract into two xor and
+//    two 64-bit additions per coefficient (see the accumulator init).
+//  * with two waves per SIMD nothing hides an LDS round trip but the wave's own instruction stream, and round 2's counters show the
+//    waves waiting to ISSUE LDS instructions 19 % of their time.  The transform (fft_dev.h, canonical form v2) therefore reads
+//    ONE table, 16 entries per lane and transform, in two batches issued a whole decomposition step / first pass ahead of their
+//    use; its first pass has lane-independent twiddles (compile-time constants in SGPRs) and the twist costs no pass of its own.
 //  * a burst of 25 key loads blocks the in-order wave for as long as the L1 takes to accept them (~150 cycles each with one
-//    workgroup on the CU: 28 % of a lone wave's time).  15 of the 25 GGSW entries of a level are therefore requested one or two
-//    at a time BETWEEN the instructions of the transpose and of the second DFT16, into the registers the twiddle buffers have
-//    just left; the other 10 right after the digit stores, into the registers of the transform working set, before the
-//    exchange barrier.
-//  * key rows are addressed as (scalar row pointer) + (16 * point) so no 64-bit vector address arithmetic is issued;
-//    LDS addresses are (one base per lane) + constants, recomputed per phase from an opaque lane index so the
-//    compiler does not keep dozens of them live across the 669-iteration loop.
+//    workgroup on the CU).  15 of the 25 GGSW entries of a level are therefore requested one or two at a time BETWEEN the
+//    instructions of the transpose and of the second pass, into the registers the table entries have just left; the other 10
+//    right after the digit stores, into the registers of the transform working set, before the exchange barrier.
+//  * key rows and parking slots are addressed as (scalar base) + (16 * lane) through raw buffer instructions: no 64-bit vector
+//    address arithmetic; LDS addresses are (one base per lane) + constants, recomputed per phase from an opaque lane index so the
+//    compiler does not keep dozens of them live across the 669-iteration loop (lane roles for the epilogue included: that alone
+//    freed 19 VGPRs).
 #pragma once
 #include "fft_dev.h"
 #include "kern_extprod.h"
@@ -100,13 +98,6 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
     const __amdgpu_buffer_rsrc_t park_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.park, 0, (int)A.park_bytes, 0x00020000);
     const unsigned park_wg = blockIdx.x * (unsigned)(BR16_PARK_WORDS_PER_WG * 8);                       // wave-uniform
     __syncthreads();   // tables visible
-#if defined(BR16_STAGGER_SLEEP) && BR16_STAGGER_SLEEP > 0
-    // developer experiment: start every second generation of workgroups a fraction of a level later, so that the two
-    // workgroups of a CU run their key-load phase and their transform phase against each other instead of in phase
-    if ((blockIdx.x >> BR16_STAGGER_SHIFT) & 1) {
-        for (int i = 0; i < BR16_STAGGER_SLEEP; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 
     constexpr unsigned GGSW_BYTES = LEVELS * K1 * K1 * FHE_H * 16;   // one GGSW of the Fourier BSK
     // the whole Fourier BSK as one raw buffer (< 2^31 bytes for every supported parameter set: checked by the launcher)

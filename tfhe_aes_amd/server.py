@@ -54,13 +54,18 @@ def _to_space(arr: np.ndarray, ref):
 class Server:
     """``Server::new`` (server.rs:32): takes the evaluation keys by value; the engine copies them to HBM."""
 
-    def __init__(self, keys: ServerKeys, device: int = 0, engine: _native.Engine | None = None):
-        self.params: WopbsParameters = keys.params
-        self.engine = engine or _native.Engine(keys.params, device)
+    def __init__(self, keys: ServerKeys | None, device: int = 0, engine: _native.Engine | None = None, clone_from: "Server | None" = None):
+        """`clone_from`: take the converted key images from another Server's context, device to device (fheaes_clone_keys),
+        instead of uploading `keys` again (which may then be None)."""
+        self.params: WopbsParameters = clone_from.params if clone_from is not None else keys.params
+        self.engine = engine or _native.Engine(self.params, device)
         # device temporaries this wrapper created for calls that are still in flight on the engine's stream; they must
         # outlive the kernels that read them (torch's caching allocator would hand the block out again): freed in synchronize()
         self._inflight = []
-        self.engine.upload_keys(np.ascontiguousarray(keys.ksk), np.ascontiguousarray(keys.bsk), np.ascontiguousarray(keys.pfpksk))
+        if clone_from is not None:
+            self.engine.clone_keys_from(clone_from.engine)
+        else:
+            self.engine.upload_keys(np.ascontiguousarray(keys.ksk), np.ascontiguousarray(keys.bsk), np.ascontiguousarray(keys.pfpksk))
 
     # ---- S-Box front end --------------------------------------------------------
     def many_wopbs_without_padding(self, ct_in, luts):
@@ -133,3 +138,61 @@ class Server:
     def synchronize(self):
         self.engine.synchronize()
         self._inflight.clear()
+
+
+class ServerGroup:
+    """Several engine contexts behind one `Server`-shaped object: what the reference does with rayon over CTR blocks
+    (main.rs:55-64, one `&Server` shared by the worker threads) done with one context per GPU -- or several on one GPU --
+    and one host thread per context.  Keys are uploaded ONCE (context 0) and cloned device to device into the others
+    (fheaes_clone_keys: xGMI between GPUs).  Blocks are sharded contiguously, block i -> context i * G / n (dist.shard_blocks);
+    no data moves between contexts.  The Rust counterpart is `GpuServerGroup` in integration/rust_shim/src/lib.rs; the
+    one-process-per-GPU path of bench.py (torch.distributed, RCCL broadcast of the seeded keys) is the other way to the same split."""
+
+    def __init__(self, keys: ServerKeys, devices=(0,)):
+        if not devices:
+            raise ValueError("at least one device")
+        self.params = keys.params
+        self.servers = [Server(keys, device=devices[0])]
+        for d in devices[1:]:
+            self.servers.append(Server(None, device=d, clone_from=self.servers[0]))
+
+    def _fan_out(self, fn, state):
+        import threading
+
+        from .dist import shard_blocks
+
+        n, g = int(state.shape[0]), len(self.servers)
+        errs = [None] * g
+
+        def work(i):
+            lo, hi = shard_blocks(n, g, i)
+            try:
+                if hi > lo:
+                    fn(self.servers[i], state[lo:hi], lo)
+                    self.servers[i].synchronize()
+            except Exception as e:       # surfaced below, on the caller's thread
+                errs[i] = e
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(g)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+        return state
+
+    def aes_encrypt(self, round_keys, state):
+        """[n_blocks][16][8][kN+1] in place (host arrays: every context stages its own shard)"""
+        return self._fan_out(lambda s, shard, lo: s.aes_encrypt(round_keys, shard), state)
+
+    def aes_decrypt(self, round_keys, state):
+        return self._fan_out(lambda s, shard, lo: s.aes_decrypt(round_keys, shard), state)
+
+    def add_scalar(self, state, counters):
+        counters = list(counters)
+        return self._fan_out(lambda s, shard, lo: s.add_scalar(shard, counters[lo:lo + int(shard.shape[0])]), state)
+
+    def aes_key_expansion(self, key):
+        return self.servers[0].aes_key_expansion(key)
