@@ -59,10 +59,18 @@ __device__ __forceinline__ void cmulc(double &xr, double &xi, double wr, double 
 
 // DFT of length 16 in registers, radix-2 decimation in time, natural order in and out.
 // INV = false: kernel e^{+2 pi i a (k + phi)/16}, phi = OFFSET ? 1/4 : 0; INV = true: conjugate kernel (phi = 0 only).
-// `hook(stage)` runs after butterfly stage 0..3 (a caller interleaves independent memory instructions there).
+// `hook(stage)` runs after butterfly stage 0..3 (a caller interleaves independent memory instructions there);
+// `chunk_hook(stage, c0)` after every chunk of butterflies c0 .. c0+FFT_CHUNK-1 of a stage: in the LAST stage (3) butterfly k
+// has just produced the final outputs k and k + 8, which live in registers fft_reg(k), fft_reg(k + 8) until dft16 returns
+// (natural order only after the renaming at its end) -- a caller can store them while the rest of the stage computes.
 struct FftNoHook { __device__ __forceinline__ void operator()(int) const {} };
-template <bool INV, bool OFFSET, typename Hook = FftNoHook>
-__device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], Hook hook = Hook())
+struct FftNoChunkHook { __device__ __forceinline__ void operator()(int, int) const {} };
+__device__ __forceinline__ constexpr int fft_reg(int k)       // register that holds logical position k inside dft16
+{
+    return ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);
+}
+template <bool INV, bool OFFSET, typename Hook = FftNoHook, typename ChunkHook = FftNoChunkHook>
+__device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], Hook hook = Hook(), ChunkHook chunk_hook = ChunkHook())
 {
     static_assert(!(INV && OFFSET), "the inverse applies its untwist after the transform");
     constexpr int BR[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};   // logical position -> register
@@ -117,6 +125,7 @@ __device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], Hook h
                 }
             }
             if (FFT_CHUNK_BARRIERS) __builtin_amdgcn_sched_barrier(0);
+            chunk_hook(st, c0);
         }
         hook(st);
     }

@@ -33,6 +33,18 @@
                               20 -> 268, 25 -> 297 (spills past 18); some of them ahead of the tiles-free barrier, or the late ones
                               between the digit stores: no gain. */
 #endif
+#ifndef BR16_XPOSE_IN_TWIDDLE
+#define BR16_XPOSE_IN_TWIDDLE 1    /* with BR16_STORE_IN_PASS2: 239 -> 231 ms per 16,384-bit launch; either one alone: no change */
+#endif
+#ifndef BR16_STAGE_AT_END
+#define BR16_STAGE_AT_END 1
+#endif
+#ifndef BR16_READ_IN_PASS2
+#define BR16_READ_IN_PASS2 1
+#endif
+#ifndef BR16_STORE_IN_PASS2
+#define BR16_STORE_IN_PASS2 1
+#endif
 #ifndef BR16_PARK_AUX_ST
 #define BR16_PARK_AUX_ST 0 /* cache policy bits of the parking stores (1 = sc0, 2 = nt, 16 = sc1; measured: see DESIGN.md) */
 #endif
@@ -97,6 +109,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
     // the parking slab as one raw buffer: (scalar: workgroup slab + chunk) + (16 * lane) -- no vector address arithmetic
     const __amdgpu_buffer_rsrc_t park_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.park, 0, (int)A.park_bytes, 0x00020000);
     const unsigned park_wg = blockIdx.x * (unsigned)(BR16_PARK_WORDS_PER_WG * 8);                       // wave-uniform
+#define BR16_PARK_SLOT(a) ((unsigned)(a) * (EP_THREADS * 16))
     __syncthreads();   // tables visible
 
     constexpr unsigned GGSW_BYTES = LEVELS * K1 * K1 * FHE_H * 16;   // one GGSW of the Fourier BSK
@@ -109,10 +122,30 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
     for (int i = 0; i < EP_NPH; ++i) ph_cyc[i] = 0;
     unsigned long long t_last = __builtin_readcyclecounter();
 #endif
+    // coefficient pair a of the (negated) accumulator -> the group's LDS tile (for the next rotation) and the parking slab
+    auto stage_park = [&](const int a, const int tq) {
+        uint64_t *stage = reinterpret_cast<uint64_t *>(lds + (tq >> 4) * GROUP_TILE_DOUBLES);
+        stage[16 * a + (tq & 15)] = lo[a];
+        stage[256 + 16 * a + (tq & 15)] = hi[a];
+        ep_u32x4 v;
+        v[0] = (uint32_t)lo[a]; v[1] = (uint32_t)(lo[a] >> 32); v[2] = (uint32_t)hi[a]; v[3] = (uint32_t)(hi[a] >> 32);
+        __builtin_amdgcn_raw_buffer_store_b128(v, park_rsrc, (unsigned)tq * 16u, park_wg + BR16_PARK_SLOT(a), BR16_PARK_AUX_ST);
+    };
+#if BR16_STAGE_AT_END
+    {
+        const int tq = br16_opaque_tid();
+#pragma unroll
+        for (int a = 0; a < 16; ++a) stage_park(a, tq);
+    }
+#endif
     for (uint32_t it = 0; it < A.iters; ++it) {
         const int t = mod_switch_1024(a_next);
         a_next = lwe[it + 1];                                    // one iteration ahead (the last one reads the body: unused)
+#ifdef BR16_ABL_SAMEKEY
+        const unsigned g_bytes = (it & 1) * GGSW_BYTES;          // developer ablation (wrong results): two L2-resident GGSWs = a 100 % L2 hit rate
+#else
         const unsigned g_bytes = it * GGSW_BYTES;                // wave-uniform byte offset of this iteration's GGSW
+#endif
 
         // ---- accumulator -> tile and parking slab; d = acc * X^t - acc; first (least significant) digit -----------
         uint32_t st_lo[16], st_hi[16];
@@ -123,17 +156,10 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             const int tq = br16_opaque_tid();
             const int bq_ = tq & 15;
             uint64_t *stage = reinterpret_cast<uint64_t *>(lds + (tq >> 4) * GROUP_TILE_DOUBLES);
+#if !BR16_STAGE_AT_END
 #pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                stage[16 * a + bq_] = lo[a];
-                stage[256 + 16 * a + bq_] = hi[a];
-            }
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                ep_u32x4 v;
-                v[0] = (uint32_t)lo[a]; v[1] = (uint32_t)(lo[a] >> 32); v[2] = (uint32_t)hi[a]; v[3] = (uint32_t)(hi[a] >> 32);
-                __builtin_amdgcn_raw_buffer_store_b128(v, park_rsrc, (unsigned)tq * 16u, park_wg + (unsigned)a * (EP_THREADS * 16), BR16_PARK_AUX_ST);
-            }
+            for (int a = 0; a < 16; ++a) stage_park(a, tq);
+#endif
             wave_lds_sync();
             fft_tw_load8(w0, tw, bq_, FHE_TW_STRIDE);             // first half of the lane's table column (T[0..7][b]): lands during the rotation
             __builtin_amdgcn_sched_barrier(0);
@@ -180,8 +206,10 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             dft16<false, true>(xr, xi);
 #endif
             __builtin_amdgcn_sched_barrier(0);
+#if !BR16_XPOSE_IN_TWIDDLE
             fft_tw_mul<false, 8>(xr, xi, w0);
             fft_tw_mul<false, 8>(xr + 8, xi + 8, w1);
+#endif
             EP_STAMP(2);
             const unsigned gl_bytes = g_bytes + (unsigned)l * (K1 * K1 * FHE_H * 16);   // scalar; the lane adds 16 * point
             double2 bm[K1][K1];
@@ -219,12 +247,32 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 #endif
 #pragma unroll
                 for (int k1 = 0; k1 < 16; ++k1) {
+#if BR16_XPOSE_IN_TWIDDLE
+                    // each value leaves for the transpose tile as soon as its twiddle multiply is done: 16 stores spread over 64
+                    // vector instructions instead of a burst
+                    if (k1 < 8) cmul(xr[k1], xi[k1], w0[k1].x, w0[k1].y); else cmul(xr[k1], xi[k1], w1[k1 - 8].x, w1[k1 - 8].y);
+#endif
                     double2 v; v.x = xr[k1]; v.y = xi[k1];
                     *reinterpret_cast<double2 *>(tile + 2 * (k1 * 17 + bq_)) = v;
+#if BR16_XPOSE_IN_TWIDDLE
+                    if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#endif
                     if (NE && k1 == 7) { __builtin_amdgcn_sched_barrier(0); early(0); }
                 }
                 if (NE) { __builtin_amdgcn_sched_barrier(0); early(1); }
                 wave_lds_sync();
+#if BR16_READ_IN_PASS2 && BR16_STORE_IN_PASS2
+                // transposed reads in the order the first butterfly stage consumes them (registers fft_reg(0), fft_reg(1), ...), and
+                // NO wait behind them: the butterflies start as the pairs arrive.  The group's reads must all have been issued and
+                // returned before its first digit store reuses the tile: that wait sits in front of that store (stage 3), by when it is free.
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int c = fft_reg(q);
+                    double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
+                    xr[c] = v.x; xi[c] = v.y;
+                }
+                if (NE) { __builtin_amdgcn_sched_barrier(0); early(2); }
+#else
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
@@ -232,20 +280,45 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
                 }
                 if (NE) { __builtin_amdgcn_sched_barrier(0); early(2); }
                 wave_lds_sync();
+#endif
 #if FFT_XPOSE_PRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
+#if BR16_STORE_IN_PASS2
+                // the transformed digits leave for the tile as the last butterfly stage produces them (outputs k and k + 8 of butterfly
+                // k), instead of as a burst of 16 stores behind the transform: the LDS queue is what the waves of a CU wait for most
+                dft16<false, false>(xr, xi, [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } },
+                                    [&](const int stage, const int c0) {
+                                        if (stage != 3) return;
+#if BR16_READ_IN_PASS2
+                                        if (c0 == 0) wave_lds_sync();      // every lane of the group has its transposed values (see the reads)
+#endif
+#pragma unroll
+                                        for (int j = 0; j < FFT_CHUNK; ++j) {
+#pragma unroll
+                                            for (int h = 0; h < 2; ++h) {
+                                                const int k2 = c0 + j + 8 * h;
+                                                double2 v; v.x = xr[fft_reg(k2)]; v.y = xi[fft_reg(k2)];
+                                                *reinterpret_cast<double2 *>(tile + 2 * (bq_ + 16 * k2)) = v;
+                                            }
+                                        }
+                                        __builtin_amdgcn_sched_barrier(0);
+                                    });
+#else
                 dft16<false, false>(xr, xi, [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } });
+#endif
             }
 #endif
             EP_STAMP(4);
             // store the transformed digits, then request the remaining GGSW entries of this level into the registers the
             // working set has just left
+#if !BR16_STORE_IN_PASS2 || defined(BR16_ABL_NOFFT) || defined(BR16_ABL_NOXPOSE)
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {
                 double2 v; v.x = xr[k2]; v.y = xi[k2];
                 *reinterpret_cast<double2 *>(tile + 2 * (bq_ + 16 * k2)) = v;
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
             key_rows(NE, K1 * K1);
             EP_STAMP(5);
@@ -313,7 +386,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
         ulonglong2 pk[16];
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
-            const ep_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(park_rsrc, (unsigned)tq * 16u, park_wg + (unsigned)a * (EP_THREADS * 16), BR16_PARK_AUX_LD);
+            const ep_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(park_rsrc, (unsigned)tq * 16u, park_wg + BR16_PARK_SLOT(a), BR16_PARK_AUX_LD);
             pk[a].x = ((unsigned long long)v[1] << 32) | v[0];
             pk[a].y = ((unsigned long long)v[3] << 32) | v[2];
         }
@@ -346,10 +419,19 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 #pragma unroll
         for (int a = 1; a < 16; ++a) cmulc(xr[a], xi[a], FHE_PSI16_RE[a], FHE_PSI16_IM[a]);
         EP_STAMP(9);
+#if BR16_STAGE_AT_END
+        wave_lds_sync();     // the inverse transform's transposed reads of this tile are complete in every lane of the group
+#endif
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
             lo[a] = torus_acc(pk[a].x, -xr[a]);               // negated accumulator: -(acc + r) = -acc + (-r)
             hi[a] = torus_acc(pk[a].y, -xi[a]);
+#if BR16_STAGE_AT_END
+            // ... and leaves for the tile and the parking slab at once: 16 LDS + 16 memory stores spread over the conversion's
+            // vector work instead of a burst at the top of the next iteration (the last iteration's copies are never read)
+            stage_park(a, tq);
+            if ((a & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         EP_STAMP(10);
     }

@@ -19,7 +19,7 @@ VARIANTS = {
     "base": [],
     "stamps": ["-DEP_STAMPS"],                       # per-phase s_memtime stamps, printed to stderr
     # ---- ablations (wrong results, timing only) ----
-    "b16_noload": ["-DBR16_ABL_NOLOAD"], "b16_nomac": ["-DBR16_ABL_NOMAC"], "b16_nomac_noload": ["-DBR16_ABL_NOMAC", "-DBR16_ABL_NOLOAD"],
+    "samekey": ["-DBR16_ABL_SAMEKEY"], "b16_noload": ["-DBR16_ABL_NOLOAD"], "b16_nomac": ["-DBR16_ABL_NOMAC"], "b16_nomac_noload": ["-DBR16_ABL_NOMAC", "-DBR16_ABL_NOLOAD"],
     "b16_nofft": ["-DBR16_ABL_NOFFT"], "b16_noxpose": ["-DBR16_ABL_NOXPOSE"],
     "b16_nofft_nomac_noload": ["-DBR16_ABL_NOFFT", "-DBR16_ABL_NOMAC", "-DBR16_ABL_NOLOAD"],
     # ---- one workgroup per CU (extra LDS) ----
@@ -33,6 +33,7 @@ VARIANTS = {
     "nobal": ["-DPBS_BALANCE=0"], "nor2": ["-DPBS_SMALL_R2=0"],
     "aux1": ["-DEP_KEY_AUX=1"], "aux2": ["-DEP_KEY_AUX=2"], "aux16": ["-DEP_KEY_AUX=16"], "aux17": ["-DEP_KEY_AUX=17"],
     "fall": ["-DEP_FENCE_MASK=0xFFF"],
+    "nostore2": ["-DBR16_STORE_IN_PASS2=0"], "noxtw": ["-DBR16_XPOSE_IN_TWIDDLE=0"], "nostage_end": ["-DBR16_STAGE_AT_END=0"], "noread2_nostage_end": ["-DBR16_READ_IN_PASS2=0", "-DBR16_STAGE_AT_END=0"], "noread2": ["-DBR16_READ_IN_PASS2=0"],
     "sched_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
     "sched_memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
     "e0": ["-DBR16_EARLY=0"],

@@ -12,15 +12,28 @@ unit = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 start = next(i for i, l in enumerate(src) if re.match(r"^_Z\w+:", l) and key in l)
 end = next(i for i in range(start, len(src)) if ".amdhsa_kernel" in src[i])
 body = src[start:end]
-# loop headers: depth-1 headers and their depth-2 children, in order
-heads = [i for i, l in enumerate(body) if "Loop Header: Depth=1" in l and "Inner" not in l]
-inner = [i for i, l in enumerate(body) if re.search(r"Parent Loop .* Depth=1", l)]
-h = heads[unit]
-b = next(i for i in inner if i > h)
-lab_h = body[h].split(":")[0].strip()
+# the iteration loop of a unit = a loop header (any depth) whose body is large and which has a rolled child loop (the levels);
+# units in listing order (the R2 unit first, then the R unit)
+def _label_line(i):           # the ".LBBn_m:" line a "Loop Header" comment belongs to (the comment may sit on a continuation line)
+    while not body[i].startswith(".LBB"):
+        i -= 1
+    return i
+
+
+hdr = [(_label_line(i), int(re.search(r"Loop Header: Depth=(\d+)", l).group(1))) for i, l in enumerate(body) if re.search(r"Loop Header: Depth=\d+", l)]
+cands = []
+for n, (i, d) in enumerate(hdr):
+    lab = body[i].split(":")[0].strip()
+    end = next((j for j in range(i + 1, len(body)) if re.search(r"s_c?branch\w*\s+" + re.escape(lab) + r"\b", body[j])), None)
+    if end is None or end - i < 1500:
+        continue
+    kids = [(j, dd) for j, dd in hdr if i < j < end and dd == d + 1]
+    big = [(j, dd) for j, dd in kids if next((e for e in range(j + 1, end) if re.search(r"s_c?branch\w*\s+" + re.escape(body[j].split(":")[0].strip()) + r"\b", body[e])), j) - j > 300]
+    if big:
+        cands.append((i, end, big[0][0]))
+h, h_end, b = cands[unit]
 lab_b = body[b].split(":")[0].strip()
 b_end = next(i for i in range(b, len(body)) if re.search(r"s_cbranch_\w+\s+" + re.escape(lab_b) + r"\b", body[i]))
-h_end = next(i for i in range(b_end, len(body)) if re.search(r"s_c?branch\w*\s+" + re.escape(lab_h) + r"\b", body[i]))
 LEVELS_M1 = 4
 
 
