@@ -39,6 +39,12 @@
 #ifndef BR16_STAGE_AT_END
 #define BR16_STAGE_AT_END 1
 #endif
+#ifndef BR16_HEAD
+#define BR16_HEAD 0        /* GGSW entries (of 25 per level) requested between the stages of pass 1 */
+#endif
+#ifndef BR16_LATE_IN_PASS2
+#define BR16_LATE_IN_PASS2 1
+#endif
 #ifndef BR16_READ_IN_PASS2
 #define BR16_READ_IN_PASS2 1
 #endif
@@ -194,23 +200,13 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             for (int c = 0; c < K1; ++c) { fr[r][c] = 0.0; fi[r][c] = 0.0; }
 
         // One decomposition level.  On entry w0 / w1 hold (or are about to receive) the lane's table column, and xr/xi the digits.
-        auto level_body = [&](const int l, const bool tiles_busy) {
+        // `last`: the most significant level (the last one of the iteration): its multiply-accumulate also requests the parked
+        // accumulator, a few chunks per row, instead of a burst of 16 loads behind it
+        ulonglong2 pk[16];
+        auto level_body = [&](const int l, const bool tiles_busy, auto last) {
             const int tq = br16_opaque_tid();
             const int bq_ = tq & 15;
             double *tile = lds + (tq >> 4) * GROUP_TILE_DOUBLES;
-            // ---- forward transform (fft_dev.h): pass 1 (frequency offset 1/4, constants only), twiddle by the table column read a
-            //      whole decomposition step ago, transpose, pass 2 ---------------------------------------------------------------
-            fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE);   // second half of the column (T[8..15][b]): lands during pass 1
-            __builtin_amdgcn_sched_barrier(0);
-#ifndef BR16_ABL_NOFFT
-            dft16<false, true>(xr, xi);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-#if !BR16_XPOSE_IN_TWIDDLE
-            fft_tw_mul<false, 8>(xr, xi, w0);
-            fft_tw_mul<false, 8>(xr + 8, xi + 8, w1);
-#endif
-            EP_STAMP(2);
             const unsigned gl_bytes = g_bytes + (unsigned)l * (K1 * K1 * FHE_H * 16);   // scalar; the lane adds 16 * point
             double2 bm[K1][K1];
             // GGSW entries [from, to) of this level (row-major: the multiply-accumulate consumes them in this order)
@@ -226,12 +222,30 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
+            // ---- forward transform (fft_dev.h): pass 1 (frequency offset 1/4, constants only), twiddle by the table column read a
+            //      whole decomposition step ago, transpose, pass 2 ---------------------------------------------------------------
+            fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE);   // second half of the column (T[8..15][b]): lands during pass 1
+            __builtin_amdgcn_sched_barrier(0);
+            // pass 1 is pure vector work (192 fused operations, no table): the first BR16_HEAD GGSW entries are requested between its
+            // stages, as many as the register file has room for while the table column and the working set are both live
+            constexpr int NH = BR16_HEAD * K1 * K1 / 25;
+#ifndef BR16_ABL_NOFFT
+            dft16<false, true>(xr, xi, [&](const int stage) { if (NH) { __builtin_amdgcn_sched_barrier(0); key_rows(NH * stage / 4, NH * (stage + 1) / 4); } });
+#else
+            key_rows(0, NH);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#if !BR16_XPOSE_IN_TWIDDLE
+            fft_tw_mul<false, 8>(xr, xi, w0);
+            fft_tw_mul<false, 8>(xr + 8, xi + 8, w1);
+#endif
+            EP_STAMP(2);
             // The first BR16_EARLY entries are requested a few at a time BETWEEN the instructions of the transpose and of the
             // second DFT16, into the registers the twiddle buffers have just left: a burst of 25 loads blocks the in-order
             // wave for as long as the L1 takes to accept them (~150 cycles each with one workgroup per CU); spaced out,
             // the same acceptance time passes under the wave's own LDS and vector work.
-            constexpr int NE = BR16_EARLY * K1 * K1 / 25, NHOOK = 7;
-            auto early = [&](const int h) { key_rows(NE * h / NHOOK, NE * (h + 1) / NHOOK); };
+            constexpr int NE = BR16_EARLY * K1 * K1 / 25 > NH ? BR16_EARLY * K1 * K1 / 25 : NH, NHOOK = 7;
+            auto early = [&](const int h) { key_rows(NH + (NE - NH) * h / NHOOK, NH + (NE - NH) * (h + 1) / NHOOK); };
             if (tiles_busy) wg_barrier_lds_only();                // every thread is done reading the previous level's digits
             EP_STAMP(3);
 #if defined(BR16_ABL_NOFFT)
@@ -303,6 +317,14 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
                                             }
                                         }
                                         __builtin_amdgcn_sched_barrier(0);
+#if BR16_LATE_IN_PASS2
+                                        // ... and the registers of the values just stored take the next share of the remaining GGSW entries
+                                        {
+                                            constexpr int NL = K1 * K1 - NE, PARTS = 8 / FFT_CHUNK;
+                                            const int part = c0 / FFT_CHUNK;
+                                            key_rows(NE + NL * part / PARTS, NE + NL * (part + 1) / PARTS);
+                                        }
+#endif
                                     });
 #else
                 dft16<false, false>(xr, xi, [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } });
@@ -320,7 +342,9 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
+#if !(BR16_LATE_IN_PASS2 && BR16_STORE_IN_PASS2) || defined(BR16_ABL_NOFFT) || defined(BR16_ABL_NOXPOSE)
             key_rows(NE, K1 * K1);
+#endif
             EP_STAMP(5);
             wg_barrier_lds_only();                                // digits of all groups visible; key loads stay in flight
             EP_STAMP(6);
@@ -355,6 +379,16 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (decltype(last)::value) {
+                    // parked accumulator back: lands during the products exchange and the inverse transform
+#pragma unroll
+                    for (int a = 16 * p / K1; a < 16 * (p + 1) / K1; ++a) {
+                        const ep_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(park_rsrc, (unsigned)tq * 16u, park_wg + BR16_PARK_SLOT(a), BR16_PARK_AUX_LD);
+                        pk[a].x = ((unsigned long long)v[1] << 32) | v[0];
+                        pk[a].y = ((unsigned long long)v[3] << 32) | v[2];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #if BR16_MAC_PRIO
             __builtin_amdgcn_s_setprio(0);
@@ -362,9 +396,10 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             EP_STAMP(7);
         };
 
-        level_body(LEVELS - 1, false);
+        // levels L-1 .. 1 rolled (transform + multiply-accumulate, then the next level's digits), the last level on its own
 #pragma unroll 1
-        for (int l = LEVELS - 2; l >= 0; --l) {
+        for (int l = LEVELS - 1; l >= 1; --l) {
+            level_body(l, l != LEVELS - 1, std::false_type{});
             {
                 const int tq = br16_opaque_tid();
                 fft_tw_load8(w0, tw, tq & 15, FHE_TW_STRIDE);     // lands during the decomposition step
@@ -376,20 +411,12 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
                 xi[a] = (double)decompose_next<BASE_LOG>(st_hi[a]);
             }
             EP_STAMP(1);
-            level_body(l, true);
         }
+        level_body(0, LEVELS > 1, std::true_type{});
 
-        // ---- parked accumulator back (lands during the products exchange and the inverse transform) ---------------
         const int tq = br16_opaque_tid();
         const int bq_ = tq & 15;
         double *tile = lds + (tq >> 4) * GROUP_TILE_DOUBLES;
-        ulonglong2 pk[16];
-#pragma unroll
-        for (int a = 0; a < 16; ++a) {
-            const ep_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(park_rsrc, (unsigned)tq * 16u, park_wg + BR16_PARK_SLOT(a), BR16_PARK_AUX_LD);
-            pk[a].x = ((unsigned long long)v[1] << 32) | v[0];
-            pk[a].y = ((unsigned long long)v[3] << 32) | v[2];
-        }
         // ---- products back to the owning groups, inverse transform, accumulate --------------------------------------
         wg_barrier_lds_only();       // every thread is done reading the last level's digits from the tiles
 #pragma unroll
@@ -411,10 +438,28 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
         // inverse transform (fft_dev.h's nega_inv, the table row read a pass ahead)
         dft16<true, false>(xr, xi);
         __builtin_amdgcn_sched_barrier(0);
+#if BR16_XPOSE_IN_TWIDDLE
+        // as in the forward transform: every value leaves for the transpose tile as soon as its twiddle multiply is done
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c >= 1) { if (c < 8) cmulc(xr[c], xi[c], w0[c].x, w0[c].y); else cmulc(xr[c], xi[c], w1[c - 8].x, w1[c - 8].y); }
+            double2 v; v.x = xr[c]; v.y = xi[c];
+            *reinterpret_cast<double2 *>(tile + 2 * (c * 17 + bq_)) = v;
+            if ((c & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = fft_reg(q);                                 // in the order the first butterfly stage consumes them
+            double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
+            xr[c] = v.x; xi[c] = v.y;
+        }
+#else
         fft_tw_mul<true, 8>(xr, xi, w0, 1);
         fft_tw_mul<true, 8>(xr + 8, xi + 8, w1);
         __builtin_amdgcn_sched_barrier(0);
         group_transpose(xr, xi, tile, bq_);
+#endif
         dft16<true, false>(xr, xi);
 #pragma unroll
         for (int a = 1; a < 16; ++a) cmulc(xr[a], xi[a], FHE_PSI16_RE[a], FHE_PSI16_IM[a]);

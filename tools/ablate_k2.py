@@ -33,7 +33,7 @@ VARIANTS = {
     "nobal": ["-DPBS_BALANCE=0"], "nor2": ["-DPBS_SMALL_R2=0"],
     "aux1": ["-DEP_KEY_AUX=1"], "aux2": ["-DEP_KEY_AUX=2"], "aux16": ["-DEP_KEY_AUX=16"], "aux17": ["-DEP_KEY_AUX=17"],
     "fall": ["-DEP_FENCE_MASK=0xFFF"],
-    "nostore2": ["-DBR16_STORE_IN_PASS2=0"], "noxtw": ["-DBR16_XPOSE_IN_TWIDDLE=0"], "nostage_end": ["-DBR16_STAGE_AT_END=0"], "noread2_nostage_end": ["-DBR16_READ_IN_PASS2=0", "-DBR16_STAGE_AT_END=0"], "noread2": ["-DBR16_READ_IN_PASS2=0"],
+    "nostore2": ["-DBR16_STORE_IN_PASS2=0"], "noxtw": ["-DBR16_XPOSE_IN_TWIDDLE=0"], "h2": ["-DBR16_HEAD=2"], "h3": ["-DBR16_HEAD=3"], "h4": ["-DBR16_HEAD=4"], "h5": ["-DBR16_HEAD=5"], "h4_e17": ["-DBR16_HEAD=4", "-DBR16_EARLY=17"], "h4_e19": ["-DBR16_HEAD=4", "-DBR16_EARLY=19"], "h6_e19": ["-DBR16_HEAD=6", "-DBR16_EARLY=19"], "nolate2": ["-DBR16_LATE_IN_PASS2=0"], "late2_e13": ["-DBR16_EARLY=13"], "late2_e10": ["-DBR16_EARLY=10"], "late2_e17": ["-DBR16_EARLY=17"], "nostage_end": ["-DBR16_STAGE_AT_END=0"], "noread2_nostage_end": ["-DBR16_READ_IN_PASS2=0", "-DBR16_STAGE_AT_END=0"], "noread2": ["-DBR16_READ_IN_PASS2=0"],
     "sched_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
     "sched_memclause": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
     "e0": ["-DBR16_EARLY=0"],

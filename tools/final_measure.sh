@@ -1,23 +1,36 @@
 #!/bin/bash
 # The measurements behind profiles/rNN_*: run as ONE gpurun call from the repo root on the GPU box,
-#   gpurun --timeout 1200 -- 'bash tools/final_measure.sh r02_v2'
-# then summarise in the container:
+#   gpurun --timeout 1200 -- 'bash tools/final_measure.sh r03_v1'
+# then copy in the container:
 #   python tools/summarize_rocprof.py gpurun_out/<tag>/prof profiles/<tag>          (kernel stats + launch table)
-#   python tools/summarize_pmc.py gpurun_out/<tag>/pmc "blind_rotate16_kernel<5, 5" profiles/<round>_pmc_blind_rotate 16384
-# Counter passes are separate rocprofv3 runs with --kernel-trace only (MI355X_MICROARCH.md, HBM section); the
-# program after `--` is python3 itself (no wrapper that would re-exec a GPU-initialised process).
+#   cp gpurun_out/<tag>/<round>_pmc_blind_rotate.json profiles/ ; cp gpurun_out/<tag>/bench.json profiles/<tag>_bench.json
+# Order: counter passes first (separate rocprofv3 runs with --kernel-trace only, MI355X_MICROARCH.md HBM section; the program
+# after `--` is python3 itself, no wrapper that would re-exec a GPU-initialised process), their summary is written next to the
+# sources it was taken from (profiles/<round>_pmc_blind_rotate.json, stamped with the sha256 of the engine sources), THEN the
+# un-profiled bench.py, whose roofline object picks traffic / valu_busy / ceiling_frac up from that file, then the kernel trace.
 set -e -o pipefail
 TAG=${1:-final}
+ROUND=${TAG%%_*}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
+# the ISA-count x issue-cost model of the blind-rotation kernel (tools/k2_dyncount.py) for roofline.ceiling_frac
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -mllvm -disable-machine-licm -I $R/include -I $R/tfhe_aes_amd/csrc -S --cuda-device-only \
+      -o /tmp/engine_final.s $R/tfhe_aes_amd/csrc/engine.hip 2> /dev/null
+python3 $R/tools/k2_dyncount.py /tmp/engine_final.s blind_rotate16_kernelILi5ELi5ELi8ELi3ELi2 1 0 | tee $O/k2_dyncount.txt
+CYC=$(grep "estimated VALU issue cycles" $O/k2_dyncount.txt | grep -o "[0-9]*$")
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-tail -1 $O/bench.json | cut -c1-400
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/prof.log 2>&1
 pmc() { name=$1; shift; timeout -k 10 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc/$name -- python3 $R/tools/run_k2.py 16384 1 > $O/pmc_$name.log 2>&1; }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
 pmc sq SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS
 pmc grbm GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum
+pmc act SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VMEM
+cd $R
+python3 tools/summarize_pmc.py $O/pmc "blind_rotate16_kernel<5, 5" profiles/${ROUND}_pmc_blind_rotate 16384 256 $CYC 609280 > $O/pmc_summary.txt
+cp profiles/${ROUND}_pmc_blind_rotate.json $O/
+cd /tmp
+python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+tail -1 $O/bench.json | cut -c1-300
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/prof.log 2>&1
 echo done
