@@ -44,7 +44,10 @@ def test_bench_two_ranks_gloo():
     assert line["unit"] == "blocks/s" and line["value"] > 0
     assert "cpu_baseline" in line and line["cpu_baseline"]["kind"] == "port"        # present for every world size
     assert line["roofline"]["bound"] == "valu_f64" and "hbm" in line["roofline"]
+    for k in ("ceiling_frac", "valu_busy", "clock_ghz", "traffic"):     # present (null unless a counter file of these very sources exists)
+        assert k in line["roofline"]
     assert "key_broadcast_gloo" in line["setup_s"]
+    assert line["ctr_iteration_with_add_scalar"] is None and line["configs4_decrypt_32_blocks"] is None      # N=1 extras only
 
 
 def test_bench_one_rank_through_rccl():
@@ -71,6 +74,22 @@ def test_bench_one_rank_through_rccl():
     r = line["rccl_one_rank"]
     assert r["ranks"] == 1 and r["key_broadcast_intact"] is True and r["elapsed_all_reduce_max_ok"] is True
     assert line["n_gpus"] == 1 and line["verified_vs_aes"] is True
+
+
+def test_bench_single_rank_line_has_the_extra_verified_steps():
+    """the default N=1 line also reports the reference's whole CTR iteration and the configs[4] decrypt shard (32 blocks), both
+    verified against AES (toy parameters here: the shapes and the verification, not the numbers)"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--params", "toy", "--blocks", "32", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                         cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert line["verified_vs_aes"] is True
+    ctr, dec = line["ctr_iteration_with_add_scalar"], line["configs4_decrypt_32_blocks"]
+    assert ctr["verified_vs_aes"] is True and ctr["blocks_per_s"] > 0
+    assert dec["verified_vs_aes"] is True and dec["blocks_per_s"] > 0 and dec["k2_launches"] == 19 and dec["k2_bits_per_launch"] == 32 * 128
 
 
 def test_bench_refuses_world_size_mismatch():
