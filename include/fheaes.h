@@ -96,6 +96,26 @@ int fheaes_upload_keys_seeded(fheaes_ctx *ctx, const uint32_t *mask_key, const u
  * thread per context (contexts are independent: own stream, own workspace; calls on ONE context are serialised by its lock).
  * Both contexts must have been created with the same parameter set. */
 int fheaes_clone_keys(fheaes_ctx *dst, fheaes_ctx *src);
+/* How the last fheaes_clone_keys INTO `ctx` moved the key images: `path` = FHEAES_CLONE_NONE (no clone yet), _SAME_DEVICE (HBM copy),
+ * _PEER (hipDeviceCanAccessPeer said yes and peer access is enabled: hipMemcpyPeerAsync is a direct xGMI transfer) or _STAGED (no
+ * peer access between the two devices: the runtime stages the copy through host memory); `bytes` moved and wall `seconds` of the
+ * copies.  Any of the three out-pointers may be NULL.  (The cross-device paths have not run on hardware yet: a builder's box has
+ * one GPU.  The reference has no counterpart: its rayon workers share one `&Server` in host memory, main.rs:55-64.) */
+#define FHEAES_CLONE_NONE 0
+#define FHEAES_CLONE_SAME_DEVICE 1
+#define FHEAES_CLONE_PEER 2
+#define FHEAES_CLONE_STAGED 3
+int fheaes_clone_info(fheaes_ctx *ctx, int *path, uint64_t *bytes, double *seconds);
+
+/* ---- noise guard ---------------------------------------------------------------- */
+/* The reference builds tfhe-rs with `noise-asserts` (Cargo.toml:7) under MaxNoiseLevel::new(5) (client.rs:92): a sum of more than
+ * five nominal-noise ciphertexts between two bootstraps panics (many_wopbs.rs:101-108 resets every WoPBS output to NOMINAL).  The
+ * engine's linear layers (MixColumns + AddRoundKey = 4 + 1, the key-expansion sums = 2) count the same way: a schedule that would
+ * exceed the limit is refused with FHEAES_ERR_INVALID instead of producing undecryptable words, and the highest level any call on
+ * this context has produced can be read back.  Callers that add ciphertext words themselves (the stage-level entry points hand out
+ * raw uint64 words, which carry no metadata) keep their own count, as users of tfhe-rs' `unchecked_*` do. */
+#define FHEAES_MAX_NOISE_LEVEL 5
+int fheaes_noise_level_seen(fheaes_ctx *ctx, uint32_t *max_seen, uint32_t *limit);
 
 /* ---- stream / sync / workspace ------------------------------------------------- */
 int fheaes_set_stream(fheaes_ctx *ctx, void *hip_stream); /* NULL: the context's own stream */

@@ -114,3 +114,45 @@ def test_fft_constants_header_matches_the_twiddle_table():
     for t in (_native.get_twiddles(), orc.twiddles()):
         assert np.array_equal(np.array(arrays["FHE_PSI16_RE"]).view(np.uint64), np.ascontiguousarray(t[::16, 0][:32]).view(np.uint64))
         assert np.array_equal(np.array(arrays["FHE_PSI16_IM"]).view(np.uint64), np.ascontiguousarray(t[::16, 1][:32]).view(np.uint64))
+
+
+def test_product_build_takes_no_developer_knobs():
+    """csrc/knobs.h: the kernels' tuning knobs and wrong-result ablation switches are an #error on a product build.  The list in
+    knobs.h must name every knob the sources test, the #if chain must name every knob of the list, and the product's compile
+    flags must set none of them; the product library must not call itself a developer build."""
+    import re
+
+    text = (_build.CSRC / "knobs.h").read_text()
+    listed = set(re.findall(r"\bX\(([A-Z0-9_]+)\)", text))
+    fenced = set(re.findall(r"defined\(([A-Z0-9_]+)\)", text))
+    assert listed and listed == fenced, sorted(listed ^ fenced)
+    # every `#ifndef KNOB` / `#ifdef KNOB` / `defined(KNOB)` / `#if KNOB` of the sources is a listed knob (FHEAES_* and header guards aside)
+    used = set()
+    for path in list(_build.CSRC.glob("*.h")) + list(_build.CSRC.glob("*.hip")):
+        if path.name == "knobs.h":
+            continue
+        for line in path.read_text().splitlines():
+            m = re.match(r"\s*#\s*(?:ifndef|ifdef)\s+([A-Z][A-Z0-9_]+)", line)
+            if m:
+                used.add(m.group(1))
+            if re.match(r"\s*#\s*(?:if|elif)\b", line):
+                used.update(re.findall(r"defined\(([A-Z][A-Z0-9_]+)\)", line))
+    used = {u for u in used if not u.startswith("FHEAES_") and not u.endswith("_H")}
+    assert used <= listed, "knobs tested by the sources but not fenced in knobs.h: %s" % sorted(used - listed)
+    flags = " ".join(_build.engine_flags())
+    for knob in listed | {"FHEAES_DEV_BUILD"}:
+        assert "-D" + knob not in flags, knob
+    version = _native.load_library().fheaes_version().decode()
+    assert not version.endswith(" dev"), version
+
+
+def test_a_stray_knob_does_not_compile():
+    """one -D of a knob without -DFHEAES_DEV_BUILD must stop the build (device-side preprocessing only: fast)"""
+    import subprocess
+
+    cmd = [_build.hipcc_path(), "--offload-arch=gfx950", "-std=c++17", "-E", "--cuda-device-only", "-DBR16_ABL_NOMAC", "-I", str(_build.ROOT / "include"),
+           "-I", str(_build.CSRC), "-o", "/dev/null", str(_build.CSRC / "engine.hip")]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode != 0 and "developer knob" in res.stderr
+    res = subprocess.run(cmd[:5] + ["-DFHEAES_DEV_BUILD"] + cmd[5:], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr[-500:]

@@ -6,6 +6,7 @@ There is NO CPU fallback: if the HIP library is missing or no GPU is visible, cr
 from __future__ import annotations
 
 import ctypes
+import os
 import re
 from pathlib import Path
 
@@ -32,6 +33,8 @@ SIGNATURES = {
     "fheaes_key_body_words": (_c.c_size_t, [_ctx, _c.c_int]),
     "fheaes_upload_keys_seeded": (_c.c_int, [_ctx, _c.POINTER(_c.c_uint32), _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int]),
     "fheaes_clone_keys": (_c.c_int, [_ctx, _ctx]),
+    "fheaes_clone_info": (_c.c_int, [_ctx, _c.POINTER(_c.c_int), _u64p, _dp]),
+    "fheaes_noise_level_seen": (_c.c_int, [_ctx, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_uint32)]),
     "fheaes_set_stream": (_c.c_int, [_ctx, _c.c_void_p]),
     "fheaes_synchronize": (_c.c_int, [_ctx]),
     "fheaes_reserve": (_c.c_int, [_ctx, _c.c_uint64]),
@@ -115,10 +118,15 @@ def _ptr(x):
 class Engine:
     """Owns one ``fheaes_ctx``.  Thin: argument marshalling and error translation only."""
 
-    def __init__(self, params: WopbsParameters, device: int = 0):
+    def __init__(self, params: WopbsParameters, device: int = 0, allow_dev_build: bool = False):
         self.params = params
         self._lib = load_library()
         self._h = _ctx()
+        # a library built with developer knobs (csrc/knobs.h: possibly a wrong-result ablation) says so in its version string
+        version = (self._lib.fheaes_version() or b"").decode()
+        if version.endswith(" dev") and not (allow_dev_build or os.environ.get("FHEAES_ALLOW_DEV_BUILD") == "1"):
+            raise RuntimeError("libfheaes.so is a developer build (%r): rebuild it with tfhe_aes_amd._build.build_engine(force=True), or pass "
+                               "allow_dev_build=True / FHEAES_ALLOW_DEV_BUILD=1 if that is what you mean to run" % version)
         cp = params.c_struct()
         rc = self._lib.fheaes_create(ctypes.byref(cp), device, ctypes.byref(self._h))
         if rc != 0:
@@ -172,6 +180,18 @@ class Engine:
         """device-to-device copy of `other`'s converted key images into this context (fheaes_clone_keys): one PCIe upload serves
         several contexts -- on other GPUs (over xGMI) or on the same one (independent streams and workspaces)"""
         self._check(self._lib.fheaes_clone_keys(self._h, other._h))
+
+    def clone_info(self) -> dict:
+        """how the last clone_keys_from() into this context moved the keys: {"path": "none" | "same_device" | "peer" | "staged", "bytes", "seconds"}"""
+        path, nbytes, secs = ctypes.c_int(), ctypes.c_uint64(), ctypes.c_double()
+        self._check(self._lib.fheaes_clone_info(self._h, ctypes.byref(path), ctypes.byref(nbytes), ctypes.byref(secs)))
+        return {"path": ("none", "same_device", "peer", "staged")[path.value], "bytes": nbytes.value, "seconds": secs.value}
+
+    def noise_level_seen(self) -> tuple[int, int]:
+        """(highest number of nominal-noise ciphertexts any linear layer of this context has summed, the parameter set's limit)"""
+        seen, limit = ctypes.c_uint32(), ctypes.c_uint32()
+        self._check(self._lib.fheaes_noise_level_seen(self._h, ctypes.byref(seen), ctypes.byref(limit)))
+        return seen.value, limit.value
 
     def set_stream(self, stream_handle: int | None):
         self._check(self._lib.fheaes_set_stream(self._h, stream_handle))

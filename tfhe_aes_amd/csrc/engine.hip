@@ -8,12 +8,15 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
 
+#include "knobs.h"
 #include "fheaes.h"
 #include "fft_dev.h"
 #include "kern_extprod.h"
@@ -22,7 +25,7 @@
 #include "kern_keyswitch.h"
 #include "kern_linear.h"
 
-#define FHEAES_VERSION_STR "fheaes-mi355x 0.1 (gfx950)"
+#define FHEAES_VERSION_STR "fheaes-mi355x 0.2 (gfx950)" FHEAES_BUILD_KIND      /* " dev" when built with developer knobs (knobs.h) */
 #define MAX_CHUNK_BITS 32768ull
 #define MAX_WOPBS_BITS 16u            /* widest radix input of many_wopbs_without_padding (LUT of 2^16 entries per output bit) */
 
@@ -33,7 +36,9 @@ std::string g_create_error;
 // not be one that another thread is overwriting.  fail() keeps a per-thread copy; the pointer fheaes_last_error returns is valid
 // until the same thread's next call into the library.
 thread_local std::string tl_error;
-thread_local const void *tl_error_ctx = nullptr;
+thread_local uint64_t tl_error_ctx_id = 0;           // id of the context tl_error belongs to (ids are never reused: a new context at a
+                                                     // destroyed one's address does not inherit its message)
+std::atomic<uint64_t> g_next_ctx_id{1};
 
 // ---------------------------------------------------------------------------------------------
 // host tables
@@ -187,6 +192,7 @@ struct DevBuf {
 
 struct fheaes_ctx {
     fheaes_params p{};
+    const uint64_t id = g_next_ctx_id.fetch_add(1);
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     std::string err;
@@ -197,6 +203,14 @@ struct fheaes_ctx {
     // shapes
     uint32_t n = 0, k = 0, k1 = 0, big = 0, big1 = 0;
     uint32_t cu_count = 256;             // compute units of the device (MI355X: 256)
+    // how the last fheaes_clone_keys INTO this context moved the key images (fheaes_clone_info)
+    int clone_path = FHEAES_CLONE_NONE;
+    uint64_t clone_bytes = 0;
+    double clone_seconds = 0.0;
+    // noise guard (the reference runs tfhe-rs with `noise-asserts` and MaxNoiseLevel::new(5), Cargo.toml:7, client.rs:92): the linear
+    // layers count how many nominal-noise ciphertexts (fresh WoPBS outputs, round keys, client encryptions) they sum into one
+    uint32_t noise_level_seen = 0;
+    int k2_home = -1;                    // blind rotation: 1 = the LDS-home form runs two workgroups per CU here (queried once), 0 = parked form
     // keys
     int8_t *ksk_frag = nullptr, *pfpksk_frag = nullptr;      // balanced key bytes in MFMA B-fragment order
     uint32_t ks_ksteps = 0, ks_coltiles = 0, pf_ksteps = 0, pf_coltiles = 0;
@@ -232,7 +246,7 @@ struct fheaes_ctx {
         va_end(ap);
         err = buf;
         tl_error = buf;
-        tl_error_ctx = this;
+        tl_error_ctx_id = id;
         return code;
     }
 };
@@ -485,7 +499,14 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         StampReport rep(c, (size_t)grid16 * 4, names16);
         a.stamps = rep.d;
 #endif
-        if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate16_kernel<5, 5, 8, 3, 2>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
+        if (c->k2_home < 0) {
+            // the LDS-home form takes exactly half of a CU's 160 KB per workgroup: use it only where the runtime really places two
+            int per_cu = 0;
+            const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blind_rotate16_kernel<5, 5, 8, 3, 2, true>, EP_THREADS, 0);
+            c->k2_home = (BR16_W3_LDS_HOME && oe == hipSuccess && per_cu >= 2) ? 1 : 0;
+        }
+        if (c->k1 == 5 && c->k2_home == 1) hipLaunchKernelGGL((blind_rotate16_kernel<5, 5, 8, 3, 2, true>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
+        else if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate16_kernel<5, 5, 8, 3, 2, false>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((blind_rotate16_kernel<2, 5, 8, 8>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
     }
     HIP_TRY(c, hipGetLastError());
@@ -546,9 +567,20 @@ int launch_vertical_packing(fheaes_ctx *c, const double2 *ggswf, uint64_t n_inpu
     return FHEAES_OK;
 }
 
+// every sum of ciphertexts between two bootstraps goes through here: refuse what tfhe-rs' noise-asserts would panic on
+int noise_guard(fheaes_ctx *c, uint32_t level, const char *what)
+{
+    if (level > c->noise_level_seen) c->noise_level_seen = level;
+    if (level > FHEAES_MAX_NOISE_LEVEL)
+        return c->fail(FHEAES_ERR_INVALID, "%s would sum %u nominal-noise ciphertexts; the parameter set allows %u (MaxNoiseLevel, client.rs:92)", what, level,
+                       (unsigned)FHEAES_MAX_NOISE_LEVEL);
+    return FHEAES_OK;
+}
+
 int launch_gather(fheaes_ctx *c, const uint64_t *src, uint32_t n_luts, const uint64_t *rk, uint64_t *out, uint64_t n_blocks, const GatherTable &t)
 {
     if (n_blocks == 0) return FHEAES_OK;
+    TRY(noise_guard(c, (uint32_t)t.terms + (rk ? 1u : 0u), "the linear layer (MixColumns / ShiftRows + AddRoundKey)"));
     StageScope sc(c, FHEAES_STAGE_LINEAR, n_blocks);
     const uint32_t bw = 8 * c->big1;
     dim3 grid((bw + 1023) / 1024, 16, (unsigned)n_blocks);
@@ -560,6 +592,7 @@ int launch_gather(fheaes_ctx *c, const uint64_t *src, uint32_t n_luts, const uin
 int launch_add_bcast(fheaes_ctx *c, uint64_t *dst, const uint64_t *src, uint64_t words_per_block, uint64_t n_blocks)
 {
     if (n_blocks == 0) return FHEAES_OK;
+    TRY(noise_guard(c, 2, "the initial AddRoundKey"));
     StageScope sc(c, FHEAES_STAGE_LINEAR, n_blocks);
     uint64_t total = words_per_block * n_blocks;
     unsigned grid = (unsigned)std::min<uint64_t>((total + 255) / 256, 16384);
@@ -570,6 +603,7 @@ int launch_add_bcast(fheaes_ctx *c, uint64_t *dst, const uint64_t *src, uint64_t
 
 int launch_add2(fheaes_ctx *c, uint64_t *dst, const uint64_t *a, const uint64_t *b, uint64_t words)
 {
+    TRY(noise_guard(c, 2, "a key-expansion word sum"));
     StageScope sc(c, FHEAES_STAGE_LINEAR, 1);
     unsigned grid = (unsigned)std::min<uint64_t>((words + 255) / 256, 16384);
     hipLaunchKernelGGL(add2_kernel, dim3(grid), dim3(256), 0, c->stream, dst, a, b, words);
@@ -681,10 +715,10 @@ const char *fheaes_version(void) { return FHEAES_VERSION_STR; }
 const char *fheaes_last_error(const fheaes_ctx *ctx)
 {
     if (!ctx) return g_create_error.c_str();
-    if (tl_error_ctx != ctx) {                   // this thread has not failed on ctx: hand out a private copy of the context's last message
+    if (tl_error_ctx_id != ctx->id) {            // this thread has not failed on ctx: hand out a private copy of the context's last message
         CtxLock lock__(ctx);
         tl_error = ctx->err;
-        tl_error_ctx = ctx;
+        tl_error_ctx_id = ctx->id;
     }
     return tl_error.c_str();
 }
@@ -937,6 +971,21 @@ int fheaes_clone_keys(fheaes_ctx *dst, fheaes_ctx *src)
     HIP_TRY(dst, hipStreamSynchronize(src->stream));            // the source's conversions are complete
     HIP_TRY(dst, hipSetDevice(dst->device));
     dst->have_keys = false;
+    dst->clone_path = FHEAES_CLONE_NONE; dst->clone_bytes = 0; dst->clone_seconds = 0.0;
+    // Between two GPUs the copy is a direct xGMI transfer only if peer access is possible AND enabled; otherwise the runtime stages
+    // it through host memory.  Ask, enable once per device pair ("already enabled" is fine), and remember which of the two it was.
+    int path = FHEAES_CLONE_SAME_DEVICE;
+    if (dst->device != src->device) {
+        path = FHEAES_CLONE_STAGED;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dst->device, src->device) == hipSuccess && can) {
+            const hipError_t pe = hipDeviceEnablePeerAccess(src->device, 0);           // the current device is dst's
+            if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) path = FHEAES_CLONE_PEER;
+        }
+        (void)hipGetLastError();                                                       // "already enabled" must not poison later HIP_TRY(hipGetLastError())
+    }
+    const auto t_clone = std::chrono::steady_clock::now();
+    uint64_t moved = 0;
     struct { void **d; const void *s; size_t bytes; size_t *have; } img[3] = {
         {(void **)&dst->ksk_frag, src->ksk_frag, src->ksk_frag_bytes, &dst->ksk_frag_bytes},
         {(void **)&dst->pfpksk_frag, src->pfpksk_frag, src->pfpksk_frag_bytes, &dst->pfpksk_frag_bytes},
@@ -950,10 +999,32 @@ int fheaes_clone_keys(fheaes_ctx *dst, fheaes_ctx *src)
         *g.have = g.bytes;
         if (dst->device == src->device) HIP_TRY(dst, hipMemcpyAsync(*g.d, g.s, g.bytes, hipMemcpyDeviceToDevice, dst->stream));
         else HIP_TRY(dst, hipMemcpyPeerAsync(*g.d, dst->device, g.s, src->device, g.bytes, dst->stream));
+        moved += g.bytes;
     }
     HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+    dst->clone_path = path; dst->clone_bytes = moved;
+    dst->clone_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_clone).count();
     dst->ks_ksteps = src->ks_ksteps; dst->ks_coltiles = src->ks_coltiles; dst->pf_ksteps = src->pf_ksteps; dst->pf_coltiles = src->pf_coltiles;
     dst->have_keys = true;
+    return FHEAES_OK;
+}
+
+int fheaes_noise_level_seen(fheaes_ctx *c, uint32_t *max_seen, uint32_t *limit)
+{
+    CtxLock lock__(c);
+    if (!c) return FHEAES_ERR_INVALID;
+    if (max_seen) *max_seen = c->noise_level_seen;
+    if (limit) *limit = FHEAES_MAX_NOISE_LEVEL;
+    return FHEAES_OK;
+}
+
+int fheaes_clone_info(fheaes_ctx *c, int *path, uint64_t *bytes, double *seconds)
+{
+    CtxLock lock__(c);
+    if (!c) return FHEAES_ERR_INVALID;
+    if (path) *path = c->clone_path;
+    if (bytes) *bytes = c->clone_bytes;
+    if (seconds) *seconds = c->clone_seconds;
     return FHEAES_OK;
 }
 

@@ -60,6 +60,28 @@
                               235 ms; stores sc1 or sc0+sc1 on top: no further change; nt STORES: 242-247 ms (slower), whatever the loads do */
 #endif
 #define BR16_PARK_WORDS_PER_WG (16 * EP_THREADS * 2)       /* 16 chunks of 16 bytes per thread (lo[a], hi[a]): 64 KB per workgroup */
+#ifndef BR16_PARK_OWNERS_ONLY
+#define BR16_PARK_OWNERS_ONLY 1   /* lane groups that own no polynomial (group 15 of a three-ciphertext unit, groups 10-15 of a two-ciphertext
+                                     one) park nothing: their buffer offset is out of range, so the store is dropped and the load returns 0
+                                     (round 3 stored and reloaded their 4 KB per group 669 times for nothing: 45 GB per launch) */
+#endif
+#ifndef BR16_W3_LDS_HOME
+#define BR16_W3_LDS_HOME 1        /* three-ciphertext units: the accumulators of wavefront 3 (groups 12-14) LIVE in LDS instead of the parking
+                                     slab -- see blind_rotate16_unit.  Needs 81,920 B of LDS per workgroup (two of them = all 160 KB of a CU);
+                                     the launcher falls back to the parked form if the runtime does not place two such workgroups on a CU */
+#endif
+#ifndef BR16_RESIDENT_HI
+#define BR16_RESIDENT_HI 0        /* 1: the upper halves hi[] of the (negated) accumulator stay in registers for the whole rotation; only lo[]
+                                     is parked (two coefficients per 16-byte chunk: 8 stores + 8 loads per lane and iteration instead of 16 + 16).
+                                     Costs 32 VGPRs, i.e. 8 of the 15 GGSW entries that BR16_EARLY keeps in flight across the transform */
+#endif
+#ifndef BR16_MAC_TAIL
+#define BR16_MAC_TAIL (BR16_RESIDENT_HI ? 5 : 0)   /* GGSW entries (of 25 per level) requested only after the multiply-accumulate has used row 0 */
+#endif
+#ifndef BR16_W1_LATE
+#define BR16_W1_LATE BR16_RESIDENT_HI
+#endif
+#define BR16_HOME_LDS_DOUBLES (2 * FHE_TW_ENTRIES + (EP_GROUPS - 1) * GROUP_TILE_DOUBLES + 3 * FHE_N)   /* table + 15 tiles + 3 accumulators = 81,920 B */
 
 __device__ __forceinline__ int br16_opaque_tid()
 {
@@ -72,10 +94,19 @@ __device__ __forceinline__ int br16_opaque_tid()
 #define BR16_PAD_DOUBLES 0     /* developer ablation: extra LDS so that only one workgroup fits a CU */
 #endif
 // One unit of work = R ciphertexts starting at `inst0`, one workgroup (the body of the kernel below).
-template <int K1, int LEVELS, int BASE_LOG, int R>
+//
+// HOME (three-ciphertext units, R * K1 = 15): group 15 owns nothing and has always computed a duplicate of group 14 (same ciphertext,
+// same polynomial).  Here it is an exact MIRROR of it: same tile, same values, same wavefront, so every LDS write of a group-15 lane
+// hits the address its group-14 twin writes in the same instruction with the same value.  That frees tile 15, and tile 15 + the LDS two
+// workgroups left unused on a CU (2 x 7,936 B) is exactly three accumulators (12,288 B): the accumulators of wavefront 3 (groups
+// 12, 13, 14) live THERE for the whole rotation -- the rotation reads them in place, the new value overwrites them in place, and
+// wavefront 3 has no parking traffic at all (a quarter of the slab's 64 KB per workgroup and iteration).
+template <int K1, int LEVELS, int BASE_LOG, int R, bool HOME = false>
 __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double *lds_all, const uint64_t inst0)
 {
     static_assert(R * K1 <= EP_GROUPS, "too many polynomials for 16 lane groups");
+    static_assert(!HOME || R * K1 == EP_GROUPS - 1, "the LDS home needs exactly one idle lane group (its tile is the home's first third)");
+    constexpr int LAST_G = R * K1 - 1, HOME_G0 = 12;          // last owner group; first group of wavefront 3
     // the twiddle table first: its addresses then fit the 16-bit offset field of the LDS instructions
     double2 *tw = reinterpret_cast<double2 *>(lds_all);
     double *lds = lds_all + 2 * FHE_TW_ENTRIES;                   // the 16 group tiles
@@ -85,6 +116,30 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
     const bool owner = g < R * K1;
     const int r_own = owner ? g / K1 : R - 1;
     const int p_own = owner ? g % K1 : K1 - 1;
+    // wave-uniform: this wavefront's accumulators live in LDS (scalar branches below)
+    const bool home_wave = HOME && __builtin_amdgcn_readfirstlane(tid) >= 16 * HOME_G0;
+    // the tile a lane's group transposes through / exchanges digits in (HOME: group 15 shares group 14's, see above)
+    auto tile_of = [&](const int tq) -> double * {
+        int gq = tq >> 4;
+        if (HOME) gq = gq < LAST_G ? gq : LAST_G;
+        return lds + gq * GROUP_TILE_DOUBLES;
+    };
+    // where the rotation reads the group's (negated) accumulator: its tile (copied there by stage_park), or its LDS home
+    auto stage_of = [&](const int tq) -> uint64_t * {
+        int gq = tq >> 4;
+        if (HOME) {
+            gq = gq < LAST_G ? gq : LAST_G;
+            const int tile_words = gq * GROUP_TILE_DOUBLES, home_words = (EP_GROUPS - 1) * GROUP_TILE_DOUBLES + (gq - HOME_G0) * FHE_N;
+            return reinterpret_cast<uint64_t *>(lds) + (gq >= HOME_G0 ? home_words : tile_words);
+        }
+        return reinterpret_cast<uint64_t *>(lds + gq * GROUP_TILE_DOUBLES);
+    };
+    // byte offset of a lane in a parking chunk; lanes that park nothing get an out-of-range offset (raw buffer: dropped / zero)
+    auto park_lane = [&](const int tq) -> unsigned {
+        if (HOME) return (tq >> 4) < HOME_G0 ? (unsigned)tq * 16u : 0x80000000u;              // wavefront 3 parks nothing
+        if (BR16_PARK_OWNERS_ONLY && R * K1 < EP_GROUPS) return (tq >> 4) < R * K1 ? (unsigned)tq * 16u : 0x80000000u;
+        return (unsigned)tq * 16u;
+    };
 
     ep_load_table(tw, A.tw);
 
@@ -130,12 +185,24 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 #endif
     // coefficient pair a of the (negated) accumulator -> the group's LDS tile (for the next rotation) and the parking slab
     auto stage_park = [&](const int a, const int tq) {
-        uint64_t *stage = reinterpret_cast<uint64_t *>(lds + (tq >> 4) * GROUP_TILE_DOUBLES);
+        uint64_t *stage = stage_of(tq);
         stage[16 * a + (tq & 15)] = lo[a];
         stage[256 + 16 * a + (tq & 15)] = hi[a];
-        ep_u32x4 v;
-        v[0] = (uint32_t)lo[a]; v[1] = (uint32_t)(lo[a] >> 32); v[2] = (uint32_t)hi[a]; v[3] = (uint32_t)(hi[a] >> 32);
-        __builtin_amdgcn_raw_buffer_store_b128(v, park_rsrc, (unsigned)tq * 16u, park_wg + BR16_PARK_SLOT(a), BR16_PARK_AUX_ST);
+#ifndef BR16_ABL_NOPARK
+#if BR16_RESIDENT_HI
+        if (a & 1) {                                             // compile-time: a is an unrolled loop index
+            ep_u32x4 v;
+            v[0] = (uint32_t)lo[a - 1]; v[1] = (uint32_t)(lo[a - 1] >> 32); v[2] = (uint32_t)lo[a]; v[3] = (uint32_t)(lo[a] >> 32);
+            __builtin_amdgcn_raw_buffer_store_b128(v, park_rsrc, park_lane(tq), park_wg + BR16_PARK_SLOT(a >> 1), BR16_PARK_AUX_ST);
+        }
+#else
+        {                                                        // (wavefront 3 of a HOME unit: out of range, it has just written its home)
+            ep_u32x4 v;
+            v[0] = (uint32_t)lo[a]; v[1] = (uint32_t)(lo[a] >> 32); v[2] = (uint32_t)hi[a]; v[3] = (uint32_t)(hi[a] >> 32);
+            __builtin_amdgcn_raw_buffer_store_b128(v, park_rsrc, park_lane(tq), park_wg + BR16_PARK_SLOT(a), BR16_PARK_AUX_ST);
+        }
+#endif
+#endif
     };
 #if BR16_STAGE_AT_END
     {
@@ -161,7 +228,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
         {
             const int tq = br16_opaque_tid();
             const int bq_ = tq & 15;
-            uint64_t *stage = reinterpret_cast<uint64_t *>(lds + (tq >> 4) * GROUP_TILE_DOUBLES);
+            uint64_t *stage = stage_of(tq);
 #if !BR16_STAGE_AT_END
 #pragma unroll
             for (int a = 0; a < 16; ++a) stage_park(a, tq);
@@ -202,11 +269,15 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
         // One decomposition level.  On entry w0 / w1 hold (or are about to receive) the lane's table column, and xr/xi the digits.
         // `last`: the most significant level (the last one of the iteration): its multiply-accumulate also requests the parked
         // accumulator, a few chunks per row, instead of a burst of 16 loads behind it
+#if BR16_RESIDENT_HI
+        uint64_t pkl[16];                                         // the parked half (lo[]) on its way back
+#else
         ulonglong2 pk[16];
+#endif
         auto level_body = [&](const int l, const bool tiles_busy, auto last) {
             const int tq = br16_opaque_tid();
             const int bq_ = tq & 15;
-            double *tile = lds + (tq >> 4) * GROUP_TILE_DOUBLES;
+            double *tile = tile_of(tq);
             const unsigned gl_bytes = g_bytes + (unsigned)l * (K1 * K1 * FHE_H * 16);   // scalar; the lane adds 16 * point
             double2 bm[K1][K1];
             // GGSW entries [from, to) of this level (row-major: the multiply-accumulate consumes them in this order)
@@ -214,6 +285,9 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 #pragma unroll
                 for (int q = 0; q < K1 * K1; ++q) {
                     if (q < from || q >= to) continue;
+#ifdef BR16_ABL_HALFKEY
+                    if (q % K1 >= 3) continue;                    // developer ablation (wrong results): 60 % of the key bytes, same arithmetic
+#endif
 #ifdef BR16_ABL_NOLOAD
                     bm[q / K1][q % K1] = make_double2((double)(tq + q), (double)(tq - q));
 #else
@@ -224,7 +298,9 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             };
             // ---- forward transform (fft_dev.h): pass 1 (frequency offset 1/4, constants only), twiddle by the table column read a
             //      whole decomposition step ago, transpose, pass 2 ---------------------------------------------------------------
+#if !BR16_W1_LATE
             fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE);   // second half of the column (T[8..15][b]): lands during pass 1
+#endif
             __builtin_amdgcn_sched_barrier(0);
             // pass 1 is pure vector work (192 fused operations, no table): the first BR16_HEAD GGSW entries are requested between its
             // stages, as many as the register file has room for while the table column and the working set are both live
@@ -245,6 +321,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             // wave for as long as the L1 takes to accept them (~150 cycles each with one workgroup per CU); spaced out,
             // the same acceptance time passes under the wave's own LDS and vector work.
             constexpr int NE = BR16_EARLY * K1 * K1 / 25 > NH ? BR16_EARLY * K1 * K1 / 25 : NH, NHOOK = 7;
+            constexpr int NT = BR16_MAC_TAIL * K1 * K1 / 25;    // the last NT entries (of the last rows) are requested from inside the multiply-accumulate
             auto early = [&](const int h) { key_rows(NH + (NE - NH) * h / NHOOK, NH + (NE - NH) * (h + 1) / NHOOK); };
             if (tiles_busy) wg_barrier_lds_only();                // every thread is done reading the previous level's digits
             EP_STAMP(3);
@@ -261,6 +338,11 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 #endif
 #pragma unroll
                 for (int k1 = 0; k1 < 16; ++k1) {
+#if BR16_W1_LATE
+                    // the second half of the table column is requested only now (it lands during the first eight multiplies): while pass 1
+                    // runs the registers hold one half of the column, not both
+                    if (k1 == 0) { fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE); __builtin_amdgcn_sched_barrier(0); }
+#endif
 #if BR16_XPOSE_IN_TWIDDLE
                     // each value leaves for the transpose tile as soon as its twiddle multiply is done: 16 stores spread over 64
                     // vector instructions instead of a burst
@@ -320,7 +402,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 #if BR16_LATE_IN_PASS2
                                         // ... and the registers of the values just stored take the next share of the remaining GGSW entries
                                         {
-                                            constexpr int NL = K1 * K1 - NE, PARTS = 8 / FFT_CHUNK;
+                                            constexpr int NL = K1 * K1 - NE - NT, PARTS = 8 / FFT_CHUNK;
                                             const int part = c0 / FFT_CHUNK;
                                             key_rows(NE + NL * part / PARTS, NE + NL * (part + 1) / PARTS);
                                         }
@@ -343,7 +425,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #if !(BR16_LATE_IN_PASS2 && BR16_STORE_IN_PASS2) || defined(BR16_ABL_NOFFT) || defined(BR16_ABL_NOXPOSE)
-            key_rows(NE, K1 * K1);
+            key_rows(NE, K1 * K1 - NT);
 #endif
             EP_STAMP(5);
             wg_barrier_lds_only();                                // digits of all groups visible; key loads stay in flight
@@ -372,21 +454,45 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
                 for (int r = 0; r < R; ++r) {
 #pragma unroll
                     for (int c = 0; c < K1; ++c) {
-                        fr[r][c] = __builtin_fma(d[r].x, bm[p][c].x, fr[r][c]);
-                        fr[r][c] = __builtin_fma(-d[r].y, bm[p][c].y, fr[r][c]);
-                        fi[r][c] = __builtin_fma(d[r].x, bm[p][c].y, fi[r][c]);
-                        fi[r][c] = __builtin_fma(d[r].y, bm[p][c].x, fi[r][c]);
+#ifdef BR16_ABL_HALFKEY
+                        const double2 kq = bm[p][c >= 3 ? c - 3 : c];
+#else
+                        const double2 kq = bm[p][c];
+#endif
+                        fr[r][c] = __builtin_fma(d[r].x, kq.x, fr[r][c]);
+                        fr[r][c] = __builtin_fma(-d[r].y, kq.y, fr[r][c]);
+                        fi[r][c] = __builtin_fma(d[r].x, kq.y, fi[r][c]);
+                        fi[r][c] = __builtin_fma(d[r].y, kq.x, fi[r][c]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (NT && p == 0) key_rows(K1 * K1 - NT, K1 * K1);      // into the registers row 0 has just left
                 if constexpr (decltype(last)::value) {
                     // parked accumulator back: lands during the products exchange and the inverse transform
+#if BR16_RESIDENT_HI
 #pragma unroll
-                    for (int a = 16 * p / K1; a < 16 * (p + 1) / K1; ++a) {
-                        const ep_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(park_rsrc, (unsigned)tq * 16u, park_wg + BR16_PARK_SLOT(a), BR16_PARK_AUX_LD);
-                        pk[a].x = ((unsigned long long)v[1] << 32) | v[0];
-                        pk[a].y = ((unsigned long long)v[3] << 32) | v[2];
+                    for (int j = 8 * p / K1; j < 8 * (p + 1) / K1; ++j) {
+#ifdef BR16_ABL_NOPARK
+                        pkl[2 * j] = 0; pkl[2 * j + 1] = 0;
+#else
+                        const ep_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(park_rsrc, park_lane(tq), park_wg + BR16_PARK_SLOT(j), BR16_PARK_AUX_LD);
+                        pkl[2 * j] = ((unsigned long long)v[1] << 32) | v[0];
+                        pkl[2 * j + 1] = ((unsigned long long)v[3] << 32) | v[2];
+#endif
                     }
+#elif defined(BR16_ABL_NOPARK)
+#pragma unroll
+                    for (int a = 16 * p / K1; a < 16 * (p + 1) / K1; ++a) { pk[a].x = 0; pk[a].y = 0; }
+#else
+                    {
+#pragma unroll
+                        for (int a = 16 * p / K1; a < 16 * (p + 1) / K1; ++a) {
+                            const ep_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(park_rsrc, park_lane(tq), park_wg + BR16_PARK_SLOT(a), BR16_PARK_AUX_LD);
+                            pk[a].x = ((unsigned long long)v[1] << 32) | v[0];
+                            pk[a].y = ((unsigned long long)v[3] << 32) | v[2];
+                        }
+                    }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -416,7 +522,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 
         const int tq = br16_opaque_tid();
         const int bq_ = tq & 15;
-        double *tile = lds + (tq >> 4) * GROUP_TILE_DOUBLES;
+        double *tile = tile_of(tq);
         // ---- products back to the owning groups, inverse transform, accumulate --------------------------------------
         wg_barrier_lds_only();       // every thread is done reading the last level's digits from the tiles
 #pragma unroll
@@ -460,6 +566,17 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
         __builtin_amdgcn_sched_barrier(0);
         group_transpose(xr, xi, tile, bq_);
 #endif
+        if (home_wave) {
+            // wavefront 3 of a HOME unit: the old accumulator comes from its LDS home (the lane's own coefficients: written by this
+            // lane, no synchronisation needed), landing during the transform's last pass
+            const uint64_t *home = stage_of(tq);
+#pragma unroll
+#if BR16_RESIDENT_HI
+            for (int a = 0; a < 16; ++a) pkl[a] = home[16 * a + bq_];
+#else
+            for (int a = 0; a < 16; ++a) { pk[a].x = home[16 * a + bq_]; pk[a].y = home[256 + 16 * a + bq_]; }
+#endif
+        }
         dft16<true, false>(xr, xi);
 #pragma unroll
         for (int a = 1; a < 16; ++a) cmulc(xr[a], xi[a], FHE_PSI16_RE[a], FHE_PSI16_IM[a]);
@@ -469,8 +586,13 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 #endif
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
+#if BR16_RESIDENT_HI
+            lo[a] = torus_acc(pkl[a], -xr[a]);                // negated accumulator: -(acc + r) = -acc + (-r)
+            hi[a] = torus_acc(hi[a], -xi[a]);
+#else
             lo[a] = torus_acc(pk[a].x, -xr[a]);               // negated accumulator: -(acc + r) = -acc + (-r)
             hi[a] = torus_acc(pk[a].y, -xi[a]);
+#endif
 #if BR16_STAGE_AT_END
             // ... and leaves for the tile and the parking slab at once: 16 LDS + 16 memory stores spread over the conversion's
             // vector work instead of a burst at the top of the next iteration (the last iteration's copies are never read)
@@ -515,15 +637,18 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
 // has slots (two per CU) the launcher picks both counts so that the total is a whole number of generations and covers the batch
 // exactly: 16,384 bits = 5,120 x 3 + 512 x 2 = 11 full generations, instead of 5,462 x 3 whose eleventh generation leaves a third of
 // the CUs idle for the length of a full one.  Workgroups are dispatched in index order, so the smaller units form the last generation.
-template <int K1, int LEVELS, int BASE_LOG, int R, int R2 = 0>
+// HOME: the R-ciphertext units keep wavefront 3's accumulators in LDS (blind_rotate16_unit); the R2 units are the parked form.
+template <int K1, int LEVELS, int BASE_LOG, int R, int R2 = 0, bool HOME = false>
 __global__ __launch_bounds__(EP_THREADS, 2) void blind_rotate16_kernel(const ExtProdArgs A)
 {
-    __shared__ __attribute__((aligned(16))) double lds_all[EP_LDS_DOUBLES + BR16_PAD_DOUBLES];
+    constexpr int LDS_DOUBLES = HOME ? BR16_HOME_LDS_DOUBLES : EP_LDS_DOUBLES + BR16_PAD_DOUBLES;
+    static_assert(LDS_DOUBLES >= EP_LDS_DOUBLES && (BR16_PAD_DOUBLES > 0 || LDS_DOUBLES * 8 <= 81920), "two workgroups must fit the 160 KB of a CU");
+    __shared__ __attribute__((aligned(16))) double lds_all[LDS_DOUBLES];
     if constexpr (R2 > 0) {
         if (blockIdx.x >= A.units_main) {       // scalar branch
-            blind_rotate16_unit<K1, LEVELS, BASE_LOG, R2>(A, lds_all, (uint64_t)A.units_main * R + (uint64_t)(blockIdx.x - A.units_main) * R2);
+            blind_rotate16_unit<K1, LEVELS, BASE_LOG, R2, false>(A, lds_all, (uint64_t)A.units_main * R + (uint64_t)(blockIdx.x - A.units_main) * R2);
             return;
         }
     }
-    blind_rotate16_unit<K1, LEVELS, BASE_LOG, R>(A, lds_all, (uint64_t)blockIdx.x * R);
+    blind_rotate16_unit<K1, LEVELS, BASE_LOG, R, HOME>(A, lds_all, (uint64_t)blockIdx.x * R);
 }

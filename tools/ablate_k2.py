@@ -12,11 +12,23 @@ import numpy as np
 sys.path.insert(0, ".")
 import torch  # noqa: E402,F401  (HIP runtime first, see _native.load_library)
 
+sys.path.insert(0, "tools")
+from gpu_power import Sampler, fmt  # noqa: E402
+
 from tfhe_aes_amd import PARAM_OPT, _build, _native  # noqa: E402
 from tfhe_aes_amd.client import Client  # noqa: E402
 
 VARIANTS = {
     "base": [],
+    # ---- round 4: parking ----
+    "nohome": ["-DBR16_W3_LDS_HOME=0"],                                   # wavefront 3 parks like the others (idle lanes still skip)
+    "r3park": ["-DBR16_W3_LDS_HOME=0", "-DBR16_PARK_OWNERS_ONLY=0"],      # round-3 behaviour: every lane parks
+    "rh": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9"], "rh15": ["-DBR16_RESIDENT_HI=1"], "rh12": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=12"],
+    "rh_t0": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9", "-DBR16_MAC_TAIL=0"], "rh_w1": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9", "-DBR16_W1_LATE=0"],
+    "rh_nohome": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9", "-DBR16_W3_LDS_HOME=0"],
+    "halfkey": ["-DBR16_ABL_HALFKEY"], "halfkey_nopark": ["-DBR16_ABL_HALFKEY", "-DBR16_ABL_NOPARK"],   # 60 % of the key bytes
+    "nopark": ["-DBR16_ABL_NOPARK"], "nopark_nohome": ["-DBR16_ABL_NOPARK", "-DBR16_W3_LDS_HOME=0"],
+    "nopark_samekey": ["-DBR16_ABL_NOPARK", "-DBR16_ABL_SAMEKEY"], "nopark_noload": ["-DBR16_ABL_NOPARK", "-DBR16_ABL_NOLOAD"],
     "stamps": ["-DEP_STAMPS"],                       # per-phase s_memtime stamps, printed to stderr
     # ---- ablations (wrong results, timing only) ----
     "samekey": ["-DBR16_ABL_SAMEKEY"], "b16_noload": ["-DBR16_ABL_NOLOAD"], "b16_nomac": ["-DBR16_ABL_NOMAC"], "b16_nomac_noload": ["-DBR16_ABL_NOMAC", "-DBR16_ABL_NOLOAD"],
@@ -63,6 +75,9 @@ VARIANTS = {
 }
 
 
+RUNS = 4
+
+
 def main():
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
     names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(VARIANTS)
@@ -78,7 +93,7 @@ def main():
             so = Path(name[3:])
         else:
             so = out / ("libfheaes_%s.so" % name)
-            cmd = [_build.hipcc_path()] + _build.engine_flags() + VARIANTS[name] + ["-o", str(so), str(_build.ENGINE_SOURCES[0])]
+            cmd = [_build.hipcc_path()] + _build.engine_flags() + ["-DFHEAES_DEV_BUILD"] + VARIANTS[name] + ["-o", str(so), str(_build.ENGINE_SOURCES[0])]
             subprocess.run(cmd, check=True, capture_output=True)
         lib = ctypes.CDLL(str(so))
         for fn, (res, args) in _native.SIGNATURES.items():
@@ -92,12 +107,17 @@ def main():
         d_out = torch.empty((M, p.big1), dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         ts = []
-        for _ in range(3):
-            t = time.perf_counter()
-            assert lib.fheaes_cbs_pbs_batch(h, d_in.data_ptr(), M, 1, d_out.data_ptr(), 1) == 0
-            lib.fheaes_synchronize(h)
-            ts.append(time.perf_counter() - t)
-        print("%-16s M=%d  %.1f ms  (runs: %s)" % (name, M, 1e3 * min(ts), " ".join("%.1f" % (1e3 * x) for x in ts)), flush=True)
+        assert lib.fheaes_cbs_pbs_batch(h, d_in.data_ptr(), M, 1, d_out.data_ptr(), 1) == 0      # warm-up (workspace, clocks)
+        lib.fheaes_synchronize(h)
+        with Sampler(period=0.01) as smp:                      # socket power / shader clock while the timed launches run
+            for _ in range(RUNS):
+                t = time.perf_counter()
+                assert lib.fheaes_cbs_pbs_batch(h, d_in.data_ptr(), M, 1, d_out.data_ptr(), 1) == 0
+                lib.fheaes_synchronize(h)
+                ts.append(time.perf_counter() - t)
+        import hashlib
+        digest = hashlib.sha256(d_out.cpu().numpy().tobytes()).hexdigest()[:12]      # equal digests = bit-identical outputs (real variants must match base)
+        print("%-16s M=%d  %.1f ms  (runs: %s)  out %s  %s" % (name, M, 1e3 * min(ts), " ".join("%.1f" % (1e3 * x) for x in ts), digest, fmt(smp.summary())), flush=True)
         lib.fheaes_destroy(h)
 
 

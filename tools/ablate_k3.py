@@ -36,7 +36,7 @@ def main():
     ref = None
     for name in names:
         so = out / ("libfheaes_k3_%s.so" % name)
-        cmd = [_build.hipcc_path()] + _build.engine_flags() + VARIANTS[name] + ["-o", str(so), str(_build.ENGINE_SOURCES[0])]
+        cmd = [_build.hipcc_path()] + _build.engine_flags() + ["-DFHEAES_DEV_BUILD"] + VARIANTS[name] + ["-o", str(so), str(_build.ENGINE_SOURCES[0])]
         subprocess.run(cmd, check=True, capture_output=True)
         lib = ctypes.CDLL(str(so))
         for fn, (res, args) in _native.SIGNATURES.items():

@@ -16,7 +16,7 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 extra = sys.argv[2:]
 out = Path("gpurun_out/abl"); out.mkdir(parents=True, exist_ok=True)
 so = out / "libfheaes_lat_stamps.so"
-subprocess.run([_build.hipcc_path()] + _build.engine_flags() + ["-DEP_STAMPS"] + extra + ["-o", str(so), str(_build.ENGINE_SOURCES[0])], check=True, capture_output=True)
+subprocess.run([_build.hipcc_path()] + _build.engine_flags() + ["-DFHEAES_DEV_BUILD", "-DEP_STAMPS"] + extra + ["-o", str(so), str(_build.ENGINE_SOURCES[0])], check=True, capture_output=True)
 p = PARAM_OPT
 c = Client(1, 1, 2, params=p, seed=0xAE50001)
 keys = c.server_keys()
