@@ -159,6 +159,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # RCCL over xGMI
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        if dist.get_world_size() != world:           # what the communicator says, not what the environment promised
+            raise SystemExit("process group has %d ranks, WORLD_SIZE says %d" % (dist.get_world_size(), world))
 
     rccl1 = None
     if world == 1 and args.rccl_one_rank:
@@ -251,21 +253,47 @@ def main():
     eng.synchronize()
     eng.profile_enable(True)
     eng.profile_reset()
+    # socket power / shader clock of this rank's GPU while the timed steps run (librocm_smi64 in-process; None where it refuses)
+    sys.path.insert(0, str(ROOT / "tools"))
+    try:
+        from gpu_power import Sampler
+        sampler = Sampler(device=dev_index, period=0.05)
+    except Exception:
+        sampler = None
     barrier()
+    if sampler is not None:
+        sampler.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(rk, state, n_blocks)
     eng.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    power = None
+    if sampler is not None:
+        sampler.__exit__()
+        ps = sampler.summary()
+        if ps["samples"]:
+            power = {"avg_w": ps["power_w"], "max_w": ps["power_max_w"], "cap_w": ps["cap_w"], "sclk_mhz": ps["sclk_mhz"],
+                     "energy_j_per_step": None if ps["energy_j"] is None else ps["energy_j"] / args.steps,
+                     "note": "rank 0's GPU over the timed steps (rocm_smi socket power, shader clock, energy counter): the blind rotation runs at "
+                             "the socket's power cap, so a step takes (joules per step) / (watts)"}
     prof = eng.profile_read()
     eng.profile_enable(False)
+    own_elapsed = elapsed
+    rank_elapsed = None
     if world > 1 or rccl1 is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         if rccl1 is not None:
             rccl1["elapsed_all_reduce_max_ok"] = float(tt.item()) == elapsed
         elapsed = float(tt.item())
+    if world > 1:
+        # every rank's own time, gathered to all (rank 0 prints them): a straggler is visible in the line itself
+        mine = torch.tensor([own_elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        rank_elapsed = [float(g.item()) for g in gathered]
 
     # ---- CPU baseline (rank 0, outside the timed region; the other ranks wait at the final barrier) -----------------
     cpu = None
@@ -370,14 +398,13 @@ def main():
         tflops = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         # measured HBM-side bytes per launch: only from a PMC summary taken from these very engine sources
         from tfhe_aes_amd import _build
-        traffic, traffic_src, valu_busy, ceiling_frac, pmc_clock = None, None, None, None, None
+        traffic, traffic_src, pm = None, None, {}
         for pmc in sorted((ROOT / "profiles").glob("*pmc_blind_rotate*.json")):
             try:
                 d = json.loads(pmc.read_text())
                 if (d.get("engine_src_sha256") == _build.engine_source_hash() and d.get("bits_per_launch") == bits_per_launch
                         and d.get("params") == p.name):
-                    traffic, traffic_src = d.get("hbm_bytes_per_launch"), pmc.name
-                    valu_busy, ceiling_frac, pmc_clock = d.get("valu_busy"), d.get("ceiling_frac"), d.get("effective_clock_ghz")
+                    traffic, traffic_src, pm = d.get("hbm_bytes_per_launch"), pmc.name, d
             except Exception:
                 pass
         stage_ms = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
@@ -402,16 +429,24 @@ def main():
             "configs4_decrypt_32_blocks": dec32,
             "stage_ms_per_step": stage_ms,
             "roofline": {
-                "kernel": "blind_rotate16_kernel (blind rotation, K2)", "bound": "valu_f64",
+                "kernel": "blind_rotate_pair_kernel (blind rotation, K2)", "bound": "valu_f64",
                 "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_VALU_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "bits_per_launch": bits_per_launch,
-                # from the same source-stamped counter file (null without one): the fraction of the roof this kernel's instruction
-                # stream would reach if a vector instruction issued on every SIMD cycle at the nominal 2.4 GHz (ISA count x
-                # per-instruction issue cost, tools/k2_dyncount.py), the measured share of SIMD cycles with a vector instruction
-                # issuing (SQ_ACTIVE_INST_VALU), and the clock the chip held under this kernel: frac ~ ceiling x busy x clock / 2.4
-                "ceiling_frac": ceiling_frac, "valu_busy": valu_busy, "clock_ghz": pmc_clock,
+                "traffic_over_algorithmic": None if traffic is None else traffic / algo_bytes,
+                # from the same source-stamped counter file (null without one; tools/summarize_pmc.py says how each is derived):
+                # ceiling_frac = the fraction of the roof this instruction stream reaches with a vector instruction issuing on every SIMD
+                # cycle at 2.4 GHz (ISA count x per-opcode issue cost, tools/k2_dyncount.py); valu_issue_occupancy_model = SQ_INSTS_VALU
+                # (measured; kept raw as sq_insts_valu) x the average issue cost per vector instruction / SIMD cycles -- a MODEL of the
+                # busy share, gfx950 exposes no busy-cycle counter for the vector ALU; clock_ghz = GRBM_GUI_ACTIVE / time;
+                # model_frac = ceiling x occupancy x clock / 2.4 is what those three say `frac` should be (the profiled launch's own
+                # fraction is frac_of_profiled_launch: profiling boxes and bench boxes differ by a few per cent)
+                "ceiling_frac": pm.get("ceiling_frac"), "valu_issue_occupancy_model": pm.get("valu_issue_occupancy_model"),
+                "sq_insts_valu": pm.get("sq_insts_valu"), "clock_ghz": pm.get("effective_clock_ghz"), "model_frac": pm.get("model_frac"),
+                "frac_of_profiled_launch": None if not pm.get("avg_launch_ms_profiled") else flops / (pm["avg_launch_ms_profiled"] * 1e-3) / 1e12 / F64_VALU_PEAK_TFLOPS,
+                "l1_fill_bytes_per_clk_per_cu": pm.get("l1_fill_bytes_per_clk_per_cu"), "l2_hit_rate": pm.get("l2_hit_rate"),
+                "power": power,
                 "algorithmic_flops_per_launch": flops, "flops_per_external_product": ext_product_flops(p),
-                "note": "at 16,384 bits per launch the kernel is bound by f64 vector issue (+ LDS and L1 fill time that do not overlap it), "
+                "note": "at 16,384 bits per launch the kernel is bound by f64 vector arithmetic under the socket's power cap (see power), "
                         "not by HBM: the BSK is read once per launch",
                 "hbm": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": algo_bytes,
@@ -421,6 +456,15 @@ def main():
                         "key_bytes_moved": key_bytes_moved, "key_expand_and_convert_on_gpu": round(expand_s, 3),
                         "aes_key_expansion": None if keyexp_s is None else round(keyexp_s, 3)},
         }
+        if world > 1:
+            line["collective"] = {
+                "backend": args.backend + (" (RCCL)" if args.backend == "nccl" else ""), "world_size_seen": dist.get_world_size(),
+                "key_broadcast_s": round(bcast_s, 3), "key_broadcast_bytes": key_bytes_moved,
+                "key_broadcast_GBps": round(key_bytes_moved / max(bcast_s, 1e-9) / 1e9, 3),
+                "rank_elapsed_s": {"min": min(rank_elapsed), "max": max(rank_elapsed), "per_rank": [round(x, 4) for x in rank_elapsed]},
+                "data_path_collectives": 0,
+                "note": "keys (seeded form) and round keys are broadcast once at start-up; the timed steps exchange nothing (CTR blocks are independent)",
+            }
         if rccl1 is not None:
             rccl1["note"] = ("torch.distributed backend nccl (= RCCL) with world_size 1 on this GPU: communicator creation, the key broadcasts "
                              "and the MAX all-reduce ran through RCCL; no second GPU, so no xGMI transfer took place")

@@ -9,6 +9,10 @@ Contents
                 numbers in src/tables/table.rs (data check only, nothing is copied from it)
   oracle_toy  : sha256 of the oracle's outputs on seeded toy-parameter inputs (pins oracle + Client determinism
                 across machines; the GPU tests compare the HIP engine against the same hashes)
+  oracle_opt  : the same at the reference's real parameter set PARAM_OPT (client.rs:31-57, k = 4): keys, K1 on 35 bits, K2 on 7,
+                K3 on 3, K4, one many_sbox byte with its first words, and the exact-arithmetic check of the external product at
+                k = 4 (the f64 product's error against an exact product mod 2^64, and the hash of the f64 result) -- pins the
+                oracle's k = 4 words across machines and across any later change of the canonical arithmetic
 """
 import json
 import re
@@ -35,6 +39,56 @@ KATS = [
 ]
 EXPECTED = ["3ad77bb40d7a3660a89ecaf32466ef97", "f5d3d58503b9699de785895a96fdbaaf", "43b1cd7f598ece23881b00e3ed030688",
             "7b0c785e27e8ad3f8223207104725dd4", "69c4e0d86a7b0430d8cdb78070b4c55a"]
+
+
+def opt_section(kit=None):
+    """seeded intermediates at PARAM_OPT; `kit` = tests/conftest.py's `opt` fixture (seed 0xAE50001) when called from a test"""
+    from tfhe_aes_amd import PARAM_OPT
+
+    seed = 0xAE50001
+    from tfhe_aes_amd.client import Client
+
+    kit = kit or Kit(PARAM_OPT, seed=seed)
+    O, p = kit.oracle, kit.params
+    # a FRESH client (same seed, hence the same secret keys): the seeded encryption stream depends on how many encryptions a client has
+    # made, and the session-wide `opt` kit of the tests has made some
+    c = Client(1, kit.client.iv, kit.client.key, params=p, seed=seed)
+    g = {"seed": seed, "params": p.name}
+    g["keys"] = {"ksk": sha(kit.keys.ksk), "bsk": sha(kit.keys.bsk), "pfpksk": sha(kit.keys.pfpksk)}
+    rng = np.random.default_rng(0x0B7)
+    bits = rng.integers(0, 2, 35).astype(np.uint8)
+    x = c.encrypt_bits(bits)
+    g["input_bits"] = "".join(str(int(b)) for b in bits)
+    g["input"] = sha(x)
+    small = O.keyswitch(x)                                      # K1, 35 bits
+    g["keyswitch_35"] = sha(small)
+    pbs = O.cbs_pbs(small[:7])                                  # K2, 7 bits
+    g["cbs_pbs_7"] = sha(pbs)
+    g["cbs_pbs_first_words"] = [int(v) for v in pbs.reshape(-1)[:4]]
+    gg = O.pfpks(pbs[:3])                                       # K3, 3 bits
+    g["pfpks_3"] = sha(gg)
+    g["ggsw_fourier_3"] = sha(orc.polys_to_fourier(gg.reshape(-1, 512)))    # K4
+    xb = c.encrypt_bytes([0x53])
+    g["byte_input"] = sha(xb)
+    y = O.wopbs_batch(xb, orc.build_lutset(orc.LUTSET_ENC_ROUND))
+    g["many_sbox_0x53"] = sha(y)
+    g["many_sbox_first_words"] = [int(v) for v in y.reshape(-1)[:4]]
+    # the external product at k = 4 against exact arithmetic (tests/test_oracle_primitives.py does this at k = 1)
+    k1, level, b = p.k + 1, p.pbs_level, p.pbs_base_log
+    rng = np.random.default_rng(0xE4)
+    ggsw = rng.integers(0, 1 << 64, (level, k1, k1, 512), dtype=np.uint64)
+    d = rng.integers(0, 1 << 64, (k1, 512), dtype=np.uint64)
+    acc0 = rng.integers(0, 1 << 64, (k1, 512), dtype=np.uint64)
+    got = orc.external_product_add(p, level, b, ggsw, d, acc0)
+    want = acc0.copy()
+    for r in range(k1):
+        digs = np.array([orc.decompose(int(v), b, level) for v in d[r]], dtype=np.int64)
+        for l in range(level):
+            for cc in range(k1):
+                want[cc] += orc.negacyclic_mul_exact(digs[:, l], ggsw[l, r, cc])
+    err = (got - want).astype(np.int64)
+    g["external_product_k4"] = {"f64_result": sha(got), "exact_result": sha(want), "max_abs_error": int(np.abs(err).max())}
+    return g
 
 
 def main():
@@ -73,6 +127,7 @@ def main():
     g["aes_decrypt"] = sha(O.aes_decrypt(rk, enc))
     g["add_scalar_0x1ff"] = sha(O.add_scalar(st, 0x1FF))
     out["oracle_toy"] = g
+    out["oracle_opt"] = opt_section()
     (Path(__file__).parent / "golden.json").write_text(json.dumps(out, indent=1) + "\n")
     print("wrote golden.json")
 

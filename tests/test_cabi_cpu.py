@@ -68,9 +68,10 @@ def test_param_struct_layout_matches_header():
 
 
 def test_k2_launch_plan_covers_the_batch_in_whole_generations():
-    """host logic of engine.hip::launch_cbs_pbs (no GPU): how a blind-rotation batch is cut into workgroups.  Latency form up to 256
-    bits; one two-ciphertext unit per CU up to 2 x CUs bits; one launch of three-ciphertext units while they fit the slots (two per
-    CU); beyond that three- and two-ciphertext units that cover the batch EXACTLY in a whole number of generations"""
+    """host logic of engine.hip::launch_cbs_pbs (no GPU): how a blind-rotation batch is cut into workgroups.  Latency form (0) up to 256
+    bits; up to 768 bits one unit of kern_blindrot16.h per CU (form 1: two-ciphertext units up to 2 x CUs bits, then three); beyond
+    that the paired form (2, kern_blindrot_pair.h): one 512-thread workgroup per CU, units of six and of four ciphertexts that cover
+    the batch in a whole number of generations, the smaller ones last"""
     import ctypes as C
 
     lib = _native.load_library()
@@ -82,16 +83,21 @@ def test_k2_launch_plan_covers_the_batch_in_whole_generations():
 
     assert plan(1) == (0, 1, 1, 0, 0) and plan(256)[:3] == (0, 256, 1)
     assert plan(257) == (1, 0, 3, 129, 2) and plan(512) == (1, 0, 3, 256, 2)          # one 2-ciphertext unit per CU
-    assert plan(513)[:4] == (1, 171, 3, 0) and plan(1536)[:4] == (1, 512, 3, 0)        # fits the 512 slots
-    assert plan(16384) == (1, 5120, 3, 512, 2)                                         # BASELINE configs[2]: 11 generations
-    assert plan(4096) == (1, 1024, 3, 512, 2)                                          # a 32-block decrypt shard: 3 generations
-    assert plan(2100) == (1, 52, 3, 972, 2) and plan(32768) == (1, 10240, 3, 1024, 2)
-    assert plan(1600)[:4] == (1, 534, 3, 0)                                            # 2 generations of 2s and 3s cannot reach down to 1,600
-    for m in list(range(257, 6000, 7)) + [16383, 16385, 30000, 32768]:
+    assert plan(513)[:4] == (1, 171, 3, 0) and plan(768)[:4] == (1, 256, 3, 0)         # one 3-ciphertext unit per CU
+    assert plan(16384) == (2, 2560, 6, 256, 4)                                         # BASELINE configs[2]: 11 generations of 256
+    assert plan(4096) == (2, 512, 6, 256, 4)                                           # a 32-block decrypt shard: 3 generations
+    assert plan(1152) == (2, 64, 6, 192, 4)                                            # one add_scalar step of 128 blocks: 1 generation
+    assert plan(800) == (2, 0, 6, 200, 4) and plan(2100) == (2, 26, 6, 486, 4) and plan(32768) == (2, 5120, 6, 512, 4)
+    for m in list(range(769, 9000, 7)) + [16383, 16385, 30000, 32768]:
         form, um, rm, ut, rt = plan(m)
-        assert form == 1 and um * rm + ut * rt >= m
-        if ut and um + ut > 512:
-            assert um * 3 + ut * 2 == m and (um + ut) % 512 == 0
+        assert (form, rm, rt) == (2, 6, 4) and m <= um * 6 + ut * 4 <= m + 3
+        if um:
+            assert (um + ut) % 256 == 0                                                # whole generations of one workgroup per CU
+        else:
+            assert ut == (m + 3) // 4          # 4-ciphertext units only: no empty workgroups
+    for m in range(257, 769, 5):
+        form, um, rm, ut, rt = plan(m)
+        assert form == 1 and um * rm + ut * rt >= m and um + ut <= 256
     assert plan(530, k=1)[:4] == (1, 67, 8, 0)                                         # toy parameter set: 8 ciphertexts per unit, no tail
     for bad in ((0, 256), (16, 0)):
         f = C.c_int(); a = C.c_uint64(); b = C.c_uint32(); c = C.c_uint64(); d = C.c_uint32()

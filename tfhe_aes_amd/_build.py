@@ -56,7 +56,8 @@ def engine_flags():
 
 
 def build_engine(force: bool = False, extra=()) -> Path:
-    if force or _stale(ENGINE_SO, ENGINE_SOURCES + ENGINE_HEADERS):
+    # this file is a dependency too: it holds the compile flags (a library built before a flag changed must not be reused)
+    if force or _stale(ENGINE_SO, ENGINE_SOURCES + ENGINE_HEADERS + [Path(__file__)]):
         cmd = [hipcc_path()] + engine_flags() + list(extra) + ["-o", str(ENGINE_SO)] + [str(s) for s in ENGINE_SOURCES]
         _run(cmd)
     return ENGINE_SO
@@ -79,6 +80,8 @@ def engine_source_hash() -> str:
     for f in sorted(ENGINE_SOURCES + ENGINE_HEADERS):
         h.update(Path(f).name.encode())
         h.update(Path(f).read_bytes())
+    # ... and the compile flags (without the machine-specific include paths): the same sources under other flags are other kernels
+    h.update(" ".join(x for x in engine_flags() if not x.startswith("/")).encode())
     return h.hexdigest()
 
 

@@ -22,6 +22,7 @@
 #include "kern_extprod.h"
 #include "kern_blindrot_latency.h"
 #include "kern_blindrot16.h"
+#include "kern_blindrot_pair.h"
 #include "kern_keyswitch.h"
 #include "kern_linear.h"
 
@@ -372,11 +373,30 @@ struct StampReport {
 #ifndef PBS_SMALL_R2
 #define PBS_SMALL_R2 1
 #endif
+#ifndef K2_PAIR
+#define K2_PAIR 1                      /* batches above K2_PAIR_MIN_BITS take the paired form (kern_blindrot_pair.h): one 512-thread workgroup per CU */
+#endif
+#ifndef K2_PAIR_MIN_BITS
+#define K2_PAIR_MIN_BITS 768ull
+#endif
 struct K2Plan { int form; uint64_t units_main; uint32_t r_main; uint64_t units_tail; uint32_t r_tail; };
 K2Plan k2_plan(uint64_t m, uint32_t cu_count, uint32_t k1)
 {
     K2Plan pl{};
     if (m <= LATENCY_BATCH_BITS) { pl.form = 0; pl.units_main = m; pl.r_main = 1; return pl; }
+    if (K2_PAIR && k1 == 5 && m > K2_PAIR_MIN_BITS) {
+        // paired form: units of 6 and of 4 ciphertexts, one workgroup per CU, a whole number of generations that covers the batch
+        // (16,384 bits = 2,560 x 6 + 256 x 4 = 11 generations; 4,096 = 512 x 6 + 256 x 4 = 3; 1,152 = 64 x 6 + 192 x 4 = 1); the
+        // smaller units last
+        pl.form = 2; pl.r_main = 6; pl.r_tail = 4;
+        const uint64_t gens = (m + 6ull * cu_count - 1) / (6ull * cu_count);
+        uint64_t nu = gens * cu_count;
+        uint64_t four = 6 * nu >= m ? (6 * nu - m) / 2 : 0;      // units that can give up two of their six slots
+        if (four > nu) four = nu;
+        if (four == nu && 4 * nu > m) { nu = (m + 3) / 4; four = nu; }          // less than one generation of 4-ciphertext units
+        pl.units_tail = four; pl.units_main = nu - four;
+        return pl;
+    }
     pl.form = 1;
     pl.r_main = k1 == 5 ? 3 : 8;
     pl.units_main = (m + pl.r_main - 1) / pl.r_main;
@@ -484,6 +504,22 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         else hipLaunchKernelGGL((blind_rotate_latency_kernel<2, 5, 8>), dim3((unsigned)m), dim3(BL_THREADS), 0, c->stream, a);
         // (257..768 bits: the throughput form below with at most one workgroup per CU, 14.6 ms per launch; the round-1
         //  one-ciphertext-per-workgroup form of kern_extprod.h took 21.6 ms there and the latency form in two waves 16-18 ms)
+    } else if (k2_plan(m, c->cu_count, c->k1).form == 2) {
+        // paired throughput form (kern_blindrot_pair.h): one 512-thread workgroup per CU, 6 (or 4) ciphertexts share every key fetch
+        const K2Plan pl = k2_plan(m, c->cu_count, c->k1);
+        const unsigned gridp = (unsigned)(pl.units_main + pl.units_tail);
+        a.units_main = (uint32_t)pl.units_main;
+        const size_t park_bytes = (size_t)gridp * 2 * BRP_PARK_WORDS_PER_HALF * 8;
+        if (park_bytes > 0x7FFFFFFFull) return c->fail(FHEAES_ERR_INVALID, "internal: parking slab of %zu bytes exceeds one raw buffer", park_bytes);
+        TRY(ensure(c, c->ws_park, park_bytes));
+        a.park = (uint64_t *)c->ws_park.p; a.park_bytes = park_bytes;
+#ifdef EP_STAMPS
+        static const char *namesP[EP_NPH] = {"stage+rotate+decomp_first", "decomp_next", "fwd head", "pre-level barrier", "fwd tail (transpose+dft16)",
+                                             "digit stores+late loads", "exchange barrier", "MAC", "products exchange", "inverse fft", "convert+add", "loop head"};
+        StampReport rep(c, (size_t)gridp * 8, namesP);
+        a.stamps = rep.d;
+#endif
+        hipLaunchKernelGGL((blind_rotate_pair_kernel<5, 5, 8, 3, 2>), dim3(gridp), dim3(BRP_THREADS), 0, c->stream, a);
     } else {
         // throughput form (kern_blindrot16.h): accumulator parked in HBM between uses, key rows prefetched across the transform
         const K2Plan pl = k2_plan(m, c->cu_count, c->k1);
@@ -849,6 +885,7 @@ int fheaes_reserve(fheaes_ctx *c, uint64_t max_bits)
         // the blind rotation's parking slab for the largest launch this reservation covers (64 KB per workgroup)
         const K2Plan pl = k2_plan(bits, c->cu_count, c->k1);
         if (pl.form == 1) TRY(ensure(c, c->ws_park, (size_t)(pl.units_main + pl.units_tail) * BR16_PARK_WORDS_PER_WG * 8));
+        if (pl.form == 2) TRY(ensure(c, c->ws_park, (size_t)(pl.units_main + pl.units_tail) * 2 * BRP_PARK_WORDS_PER_HALF * 8));
     }
     return FHEAES_OK;
 }

@@ -23,6 +23,12 @@ VARIANTS = {
     # ---- round 4: parking ----
     "nohome": ["-DBR16_W3_LDS_HOME=0"],                                   # wavefront 3 parks like the others (idle lanes still skip)
     "r3park": ["-DBR16_W3_LDS_HOME=0", "-DBR16_PARK_OWNERS_ONLY=0"],      # round-3 behaviour: every lane parks
+    # ---- round 4: the paired form (kern_blindrot_pair.h, default) ----
+    "nopair": ["-DK2_PAIR=0"], "pair_norh": ["-DBRP_RESIDENT_HI=0"], "pair_norh_e12": ["-DBRP_RESIDENT_HI=0", "-DBRP_EARLY=12"], "pair_norh_e15": ["-DBRP_RESIDENT_HI=0", "-DBRP_EARLY=15"],
+    "pair_e6": ["-DBRP_EARLY=6"], "pair_e12": ["-DBRP_EARLY=12"], "pair_w1": ["-DBRP_W1_LATE=0"], "pair_norh_w1": ["-DBRP_RESIDENT_HI=0", "-DBRP_W1_LATE=0"],
+    "nopair_stamps": ["-DK2_PAIR=0", "-DEP_STAMPS"], "pair_w2": ["-DBRP_W1_LATE=2"], "pair_w2_e6": ["-DBRP_W1_LATE=2", "-DBRP_EARLY=6"], "pair_w2_e12": ["-DBRP_W1_LATE=2", "-DBRP_EARLY=12"],
+    "pair_w2_stamps": ["-DBRP_W1_LATE=2", "-DEP_STAMPS"], "pair_w2_nopark": ["-DBRP_W1_LATE=2", "-DBR16_ABL_NOPARK"], "pair_w2_noload": ["-DBRP_W1_LATE=2", "-DBR16_ABL_NOLOAD"],
+    "pair_nopark": ["-DBR16_ABL_NOPARK"], "pair_noload": ["-DBR16_ABL_NOLOAD"], "pair_stamps": ["-DEP_STAMPS"],
     "rh": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9"], "rh15": ["-DBR16_RESIDENT_HI=1"], "rh12": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=12"],
     "rh_t0": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9", "-DBR16_MAC_TAIL=0"], "rh_w1": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9", "-DBR16_W1_LATE=0"],
     "rh_nohome": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9", "-DBR16_W3_LDS_HOME=0"],

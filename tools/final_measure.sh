@@ -17,8 +17,9 @@ mkdir -p $O
 # the ISA-count x issue-cost model of the blind-rotation kernel (tools/k2_dyncount.py) for roofline.ceiling_frac
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -mllvm -disable-machine-licm -I $R/include -I $R/tfhe_aes_amd/csrc -S --cuda-device-only \
       -o /tmp/engine_final.s $R/tfhe_aes_amd/csrc/engine.hip 2> /dev/null
-python3 $R/tools/k2_dyncount.py /tmp/engine_final.s blind_rotate16_kernelILi5ELi5ELi8ELi3ELi2 1 0 | tee $O/k2_dyncount.txt
-CYC=$(grep "estimated VALU issue cycles" $O/k2_dyncount.txt | grep -o "[0-9]*$")
+python3 $R/tools/k2_dyncount.py /tmp/engine_final.s blind_rotate_pair_kernelILi5ELi5ELi8ELi3ELi2 1 0 | tee $O/k2_dyncount.txt
+# build (if stale) BEFORE anything runs under the profiler: hipcc must not be spawned from a process tree rocprofv3 has GPU-initialised
+python3 -c 'from tfhe_aes_amd import _build; _build.build_all()'
 cd /tmp && export TMPDIR=/tmp
 pmc() { name=$1; shift; timeout -k 10 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc/$name -- python3 $R/tools/run_k2.py 16384 1 > $O/pmc_$name.log 2>&1; }
 pmc fetch FETCH_SIZE
@@ -27,7 +28,8 @@ pmc sq SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_V
 pmc grbm GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum
 pmc act SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VMEM
 cd $R
-python3 tools/summarize_pmc.py $O/pmc "blind_rotate16_kernel<5, 5" profiles/${ROUND}_pmc_blind_rotate 16384 256 $CYC 609280 > $O/pmc_summary.txt
+python3 tools/summarize_pmc.py $O/pmc "blind_rotate_pair_kernel<5, 5" profiles/${ROUND}_pmc_blind_rotate 16384 --cus 256 --dyncount $O/k2_dyncount.txt \
+        --flops-per-ct-iteration 609280 --cts-per-wg 6 --waves-per-wg 8 --algorithmic-bytes 698912768 > $O/pmc_summary.txt
 cp profiles/${ROUND}_pmc_blind_rotate.json $O/
 cd /tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err

@@ -1,59 +1,97 @@
 """Summarise rocprofv3 --pmc passes (one directory per pass) for one kernel into profiles/.
-usage: python tools/summarize_pmc.py gpurun_out/pmc_k2 "blind_rotate16_kernel<5, 5" profiles/r03_pmc_blind_rotate 16384 [CUs [valu_cycles_per_wave_iteration flops_per_ciphertext_iteration]]
-HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE is in KB and reports half of a wide coalesced
-read stream on gfx950 (x2), WRITE_SIZE is exact for 16-byte stores; separate --pmc passes."""
+usage: python tools/summarize_pmc.py <pmc dir> "<kernel name substring>" profiles/<name> <bits per launch>
+           [--cus 256] [--dyncount <file written by tools/k2_dyncount.py>] [--flops-per-ct-iteration 609280] [--cts-per-wg 6] [--waves-per-wg 8]
+HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE is in KB and reports half of a wide coalesced read stream on gfx950
+(x2), WRITE_SIZE is exact for 16-byte stores; separate --pmc passes.
+
+Derived fields (round 4: each one is what its name says):
+  effective_clock_ghz          GRBM_GUI_ACTIVE / 8 XCDs / launch time
+  valu_issue_occupancy_model   share of SIMD cycles with a vector instruction issuing, MODELLED: SQ_INSTS_VALU (measured, per wave) x the
+                               average issue cost per vector instruction of this kernel's loop (tools/k2_dyncount.py: ISA count x
+                               per-opcode cycles of tools/ubench/ubench_ops) / (CUs x 4 SIMDs x cycles).  gfx950 has no busy-cycle
+                               counter for the vector ALU that rocprofv3 lists: SQ_ACTIVE_INST_VALU returns the instruction count
+                               (it equals SQ_INSTS_VALU to the digit), so round 3's `valu_busy` (that count x an assumed 4 cycles)
+                               overstated the occupancy.
+  ceiling_frac                 fraction of the f64 vector roof this instruction stream reaches with a vector instruction issuing on
+                               every SIMD cycle at 2.4 GHz: (ciphertexts per workgroup x algorithmic flops per ciphertext-iteration) /
+                               (wavefronts per workgroup x issue cycles per wave-iteration x 32 flop per SIMD-cycle)
+  model_frac                   ceiling_frac x valu_issue_occupancy_model x clock / 2.4: what the three say the roofline fraction is
+  l1_fill_bytes_per_clk_per_cu TCP_TCC_READ_REQ_sum x 128 B / CUs / cycles (the vector-memory path into a CU; ~50 is its ceiling)
+"""
+import argparse
 import csv
 import glob
 import json
+import re
 import sys
 from collections import defaultdict
 
-src, key, prefix, bits = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
+ap = argparse.ArgumentParser()
+ap.add_argument("src"); ap.add_argument("key"); ap.add_argument("prefix"); ap.add_argument("bits", type=float)
+ap.add_argument("--cus", type=float, default=256.0)
+ap.add_argument("--dyncount", default=None)
+ap.add_argument("--flops-per-ct-iteration", type=float, default=609280.0)
+ap.add_argument("--cts-per-wg", type=float, default=6.0)
+ap.add_argument("--waves-per-wg", type=float, default=8.0)
+ap.add_argument("--algorithmic-bytes", type=float, default=None)
+args = ap.parse_args()
+
 tot, n = defaultdict(float), defaultdict(int)
 dur = []
-for f in glob.glob(src + "/*/*/*_counter_collection.csv"):
+for f in glob.glob(args.src + "/*/*/*_counter_collection.csv"):
     seen = set()
     for r in csv.DictReader(open(f)):
-        if key in r["Kernel_Name"]:
+        if args.key in r["Kernel_Name"]:
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
             seen.add(r["Dispatch_Id"])
     for f2 in glob.glob(f.rsplit("/", 1)[0] + "/*_kernel_trace.csv"):
         for r in csv.DictReader(open(f2)):
-            if key in r["Kernel_Name"]:
+            if args.key in r["Kernel_Name"]:
                 dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     for c in list(tot):
         n[c] = max(n[c], len(seen))
+if not dur:
+    sys.exit("no dispatch of a kernel matching %r under %s" % (args.key, args.src))
 launch_ms = sum(dur) / len(dur)
 per = {c: v / max(1, n[c]) for c, v in tot.items()}
 fetch = per.get("FETCH_SIZE", 0) * 1024 * 2
 write = per.get("WRITE_SIZE", 0) * 1024
 out = {
-    "kernel": key, "params": "PARAM_OPT", "bits_per_launch": bits, "avg_launch_ms_profiled": launch_ms,
+    "kernel": args.key, "params": "PARAM_OPT", "bits_per_launch": args.bits, "avg_launch_ms_profiled": launch_ms,
     "hbm_bytes_per_launch": fetch + write, "fetch_bytes_corrected_x2": fetch, "write_bytes": write,
     "counters_per_launch": per,
 }
+if args.algorithmic_bytes:
+    out["algorithmic_bytes_per_launch"] = args.algorithmic_bytes
+    out["traffic_over_algorithmic"] = (fetch + write) / args.algorithmic_bytes
+cycles = None
 if "GRBM_GUI_ACTIVE" in per:
-    out["effective_clock_ghz"] = per["GRBM_GUI_ACTIVE"] / 8 / (launch_ms * 1e-3) / 1e9
+    cycles = per["GRBM_GUI_ACTIVE"] / 8.0                      # the counter sums the 8 XCDs' clocks
+    out["effective_clock_ghz"] = cycles / (launch_ms * 1e-3) / 1e9
 if "TCC_HIT_sum" in per:
     out["l2_hit_rate"] = per["TCC_HIT_sum"] / (per["TCC_HIT_sum"] + per["TCC_MISS_sum"])
 if "SQ_WAVE_CYCLES" in per:
     w = per["SQ_WAVE_CYCLES"]
     out["wave_time_split"] = {"active": per["SQ_ACTIVE_INST_ANY"] / w, "wait_inst": per["SQ_WAIT_INST_ANY"] / w, "wait_any": per["SQ_WAIT_ANY"] / w}
-if "SQ_ACTIVE_INST_VALU" in per and "GRBM_GUI_ACTIVE" in per:
-    # SQ_ACTIVE_INST_* count in units of 4 cycles per SIMD; GRBM_GUI_ACTIVE sums the 8 XCDs' clocks; 4 SIMDs x CUs
-    cus = float(sys.argv[5]) if len(sys.argv) > 5 else 256.0
-    out["valu_busy"] = per["SQ_ACTIVE_INST_VALU"] * 4.0 / (per["GRBM_GUI_ACTIVE"] / 8.0 * cus * 4.0)
-    if "SQ_ACTIVE_INST_LDS" in per:
-        out["lds_issue_share_of_wave_time"] = per.get("SQ_WAIT_INST_LDS", 0.0) / per["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in per else None
-if len(sys.argv) > 6:
-    # ceiling: algorithmic flops per workgroup-iteration / (VALU issue cycles of its 4 waves x 32 flop per SIMD cycle);
-    # argv[6] = estimated VALU issue cycles per wave per iteration (tools/k2_dyncount.py), argv[7] = algorithmic flops per ciphertext-iteration
-    cyc, fl = float(sys.argv[6]), float(sys.argv[7])
+    if "SQ_WAIT_INST_LDS" in per:
+        out["lds_issue_share_of_wave_time"] = per["SQ_WAIT_INST_LDS"] / w
+if "TCP_TCC_READ_REQ_sum" in per and cycles:
+    out["l1_fill_bytes_per_clk_per_cu"] = per["TCP_TCC_READ_REQ_sum"] * 128.0 / args.cus / cycles
+if args.dyncount:
+    text = open(args.dyncount).read()
+    m = re.search(r"per iteration: (\d+) instructions, (\d+) VALU", text)
+    c = re.search(r"estimated VALU issue cycles per wave per iteration: (\d+)", text)
+    n_valu, cyc = float(m.group(2)), float(c.group(1))
     out["valu_issue_cycles_per_wave_iteration"] = cyc
-    out["ceiling_frac"] = 3.0 * fl / (4.0 * cyc * 32.0)
+    out["valu_instructions_per_wave_iteration"] = n_valu
+    out["ceiling_frac"] = args.cts_per_wg * args.flops_per_ct_iteration / (args.waves_per_wg * cyc * 32.0)
+    if "SQ_INSTS_VALU" in per and cycles:
+        out["sq_insts_valu"] = per["SQ_INSTS_VALU"]
+        out["valu_issue_occupancy_model"] = per["SQ_INSTS_VALU"] * (cyc / n_valu) / (args.cus * 4.0 * cycles)
+        out["model_frac"] = out["ceiling_frac"] * out["valu_issue_occupancy_model"] * out["effective_clock_ghz"] / 2.4
 sys.path.insert(0, ".")
 from tfhe_aes_amd import _build  # noqa: E402
 
 out["engine_src_sha256"] = _build.engine_source_hash()       # bench.py attaches `traffic` only to runs of the same sources
-json.dump(out, open(prefix + ".json", "w"), indent=1)
+json.dump(out, open(args.prefix + ".json", "w"), indent=1)
 print(json.dumps(out, indent=1))
