@@ -367,6 +367,50 @@ def main():
                          "(inverse S-Box + 4-LUT inverse MixColumns packing, server.rs:67-105); one step, every launch is 4,096 bits"}
         del st4
 
+    # ---- the in-process split on ONE GPU: two contexts (keys uploaded once, cloned device to device), 64 blocks each from two host
+    #      threads -- any hidden serialisation or workspace contention between contexts shows against the one-context headline ----
+    two_ctx = None
+    if rank == 0 and world == 1 and not args.ctr_add and not args.decrypt and not args.no_ctr_iteration and n_blocks >= 2 and not args.no_verify:
+        import threading
+
+        half = n_blocks // 2
+        eng2 = _native.Engine(p, device=dev_index)
+        eng2.clone_keys_from(eng)
+        ci = eng2.clone_info()
+        eng2.reserve(half * 128)
+        halves = [state[:half].clone(), state[half:2 * half].clone()]
+        engs = [eng, eng2]
+        for e_, h_ in zip(engs, halves):                 # warm-up of the second context's workspace
+            e_.aes_encrypt(rk, h_, half)
+            e_.synchronize()
+        halves = [state[:half].clone(), state[half:2 * half].clone()]
+        torch.cuda.synchronize()
+
+        def run_half(i):
+            engs[i].aes_encrypt(rk, halves[i], half)
+            engs[i].synchronize()
+
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=run_half, args=(i,)) for i in range(2)]
+        for t_ in ths:
+            t_.start()
+        for t_ in ths:
+            t_.join()
+        dt = time.perf_counter() - t0
+        ok = True
+        for hidx, bidx in ((0, 0), (1, half - 1)):
+            want = counters[hidx * half + bidx]
+            for _ in range(args.warmup + args.steps + 1):
+                want = aes128_encrypt_block(KEY, want)
+            ok = ok and client.decrypt_u128(halves[hidx][bidx].cpu().numpy().view(np.uint64)) == want
+        two_ctx = {"blocks_per_s": 2 * half / dt, "ms": 1000.0 * dt, "verified_vs_aes": bool(ok), "blocks_per_context": half,
+                   "clone": {"path": ci["path"], "bytes": ci["bytes"], "seconds": round(ci["seconds"], 4)},
+                   "note": "two fheaes contexts on this one GPU (fheaes_clone_keys: one upload, device-to-device copy of the converted key images), "
+                           "%d blocks of Server::aes_encrypt each from two host threads, concurrently: the in-process shape of the reference's rayon "
+                           "loop (main.rs:55-64); compare with `value` (one context, %d blocks)" % (half, n_blocks)}
+        eng2.close()
+        del halves
+
     # ---- BASELINE configs[1]: one AES block = 16 S-Box WoPBS in one call (latency, not throughput) ------------
     one_block_ms = None
     if rank == 0:
@@ -427,6 +471,7 @@ def main():
                                         "note": "BASELINE configs[1]: 16 S-Box WoPBS (128 bit-CBS) in one call: latency of the 669-step rotation chain"},
             "ctr_iteration_with_add_scalar": ctr_iter,
             "configs4_decrypt_32_blocks": dec32,
+            "two_contexts_64_blocks_each": two_ctx,
             "stage_ms_per_step": stage_ms,
             "roofline": {
                 "kernel": "blind_rotate_pair_kernel (blind rotation, K2)", "bound": "valu_f64",

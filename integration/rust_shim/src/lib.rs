@@ -60,6 +60,8 @@ extern "C" {
     pub fn fheaes_last_error(ctx: *const fheaes_ctx) -> *const c_char;
     pub fn fheaes_upload_keys(ctx: *mut fheaes_ctx, ksk: *const u64, bsk: *const u64, pfpksk: *const u64, memspace: c_int) -> c_int;
     pub fn fheaes_clone_keys(dst: *mut fheaes_ctx, src: *mut fheaes_ctx) -> c_int;
+    pub fn fheaes_clone_info(ctx: *mut fheaes_ctx, path: *mut c_int, bytes: *mut u64, seconds: *mut f64) -> c_int;
+    pub fn fheaes_noise_level_seen(ctx: *mut fheaes_ctx, max_seen: *mut u32, limit: *mut u32) -> c_int;
     pub fn fheaes_synchronize(ctx: *mut fheaes_ctx) -> c_int;
     pub fn fheaes_wopbs_batch(ctx: *mut fheaes_ctx, lwe_in: *const u64, n_inputs: u64, bits: u32, luts: *const u64,
                               n_luts: u32, lut_per_input: c_int, lwe_out: *mut u64, memspace: c_int) -> c_int;
@@ -241,6 +243,24 @@ impl GpuServer {
         let rc = unsafe { fheaes_clone_keys(s.ctx, self.ctx) };
         assert!(rc == 0, "fheaes_clone_keys: {}", s.last_error());
         s
+    }
+
+    /// How the keys of this (cloned) context got here: (path, bytes, seconds); path 1 = copy inside one GPU's HBM, 2 = direct xGMI
+    /// peer copy, 3 = staged through host memory because the two GPUs have no peer access (include/fheaes.h: FHEAES_CLONE_*).
+    pub fn clone_info(&self) -> (i32, u64, f64) {
+        let (mut path, mut bytes, mut secs) = (0 as c_int, 0u64, 0f64);
+        let rc = unsafe { fheaes_clone_info(self.ctx, &mut path, &mut bytes, &mut secs) };
+        assert!(rc == 0, "{}", self.last_error());
+        (path as i32, bytes, secs)
+    }
+
+    /// The engine's counterpart of tfhe-rs' `noise-asserts` (Cargo.toml:7, MaxNoiseLevel::new(5) at client.rs:92): the highest number
+    /// of nominal-noise ciphertexts any linear layer of this context has summed between two bootstraps, and the limit.
+    pub fn noise_level_seen(&self) -> (u32, u32) {
+        let (mut seen, mut limit) = (0u32, 0u32);
+        let rc = unsafe { fheaes_noise_level_seen(self.ctx, &mut seen, &mut limit) };
+        assert!(rc == 0, "{}", self.last_error());
+        (seen, limit)
     }
 
     pub fn synchronize(&self) {

@@ -31,3 +31,20 @@ def test_oracle_reproduces_golden(golden):
     assert sha(enc) == g["aes_encrypt"]
     assert sha(O.aes_decrypt(rk, enc)) == g["aes_decrypt"]
     assert sha(O.add_scalar(st, 0x1FF)) == g["add_scalar_0x1ff"]
+
+
+def test_oracle_reproduces_golden_at_param_opt(golden, opt):
+    """the PARAM_OPT section (client.rs:31-57, k = 4): seeded keys, K1 on 35 bits, K2 on 7, K3 on 3, K4, one many_sbox byte and the
+    external product against exact arithmetic -- the oracle's k = 4 words are the same on every machine and after every change"""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("make_golden", Path(__file__).parent / "golden" / "make_golden.py")
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = golden["oracle_opt"]
+    got = mg.opt_section(opt)
+    assert got == g
+    # the f64 product is an APPROXIMATE product of the same regime as tfhe-rs' fft64: error far below the gadget's payloads, not zero
+    assert 0 < g["external_product_k4"]["max_abs_error"] < 2 ** 30
+    assert g["external_product_k4"]["f64_result"] != g["external_product_k4"]["exact_result"]

@@ -247,3 +247,16 @@ def test_full_block_bit_exact_param_opt(opt):
     ctr = srv.add_scalar(st.copy(), 0x1FF)
     assert np.array_equal(ctr, O.add_scalar(st.copy(), 0x1FF))
     assert c.decrypt_u128(ctr) == (pt + 0x1FF) % (1 << 128)
+
+
+def test_noise_guard_counts_what_the_schedule_sums(toy, toy_server):
+    """the engine's counterpart of tfhe-rs' noise-asserts (Cargo.toml:7, MaxNoiseLevel::new(5) at client.rs:92): the linear layers
+    count the nominal-noise ciphertexts they sum between two bootstraps -- MixColumns (4 terms) + AddRoundKey = 5, the limit"""
+    c = toy.client
+    rk = toy_server.aes_key_expansion(c.encrypt_u128(c.key))
+    seen, limit = toy_server.engine.noise_level_seen()
+    assert limit == 5 and 2 <= seen <= 5                      # key expansion sums two words at a time (server.rs:140-148)
+    toy_server.aes_encrypt(rk, c.encrypt_u128(1))
+    assert toy_server.engine.noise_level_seen() == (5, 5)
+    toy_server.aes_decrypt(rk, c.encrypt_u128(1))
+    assert toy_server.engine.noise_level_seen() == (5, 5)

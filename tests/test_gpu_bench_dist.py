@@ -44,10 +44,20 @@ def test_bench_two_ranks_gloo():
     assert line["unit"] == "blocks/s" and line["value"] > 0
     assert "cpu_baseline" in line and line["cpu_baseline"]["kind"] == "port"        # present for every world size
     assert line["roofline"]["bound"] == "valu_f64" and "hbm" in line["roofline"]
-    for k in ("ceiling_frac", "valu_busy", "clock_ghz", "traffic"):     # present (null unless a counter file of these very sources exists)
+    # present (null unless a counter file of these very sources exists); round 3's `valu_busy` is gone: it was not a busy fraction
+    for k in ("ceiling_frac", "valu_issue_occupancy_model", "sq_insts_valu", "clock_ghz", "model_frac", "traffic", "traffic_over_algorithmic",
+              "l1_fill_bytes_per_clk_per_cu", "power"):
         assert k in line["roofline"]
+    assert "valu_busy" not in line["roofline"]
     assert "key_broadcast_gloo" in line["setup_s"]
     assert line["ctr_iteration_with_add_scalar"] is None and line["configs4_decrypt_32_blocks"] is None      # N=1 extras only
+    assert line["two_contexts_64_blocks_each"] is None
+    # a SCALE line must verify itself: what the communicator says, how the keys travelled, every rank's own time
+    col = line["collective"]
+    assert col["world_size_seen"] == 2 and col["backend"] == "gloo" and col["data_path_collectives"] == 0
+    assert col["key_broadcast_bytes"] > 0 and col["key_broadcast_GBps"] > 0
+    assert len(col["rank_elapsed_s"]["per_rank"]) == 2 and col["rank_elapsed_s"]["min"] <= col["rank_elapsed_s"]["max"]
+    assert abs(col["rank_elapsed_s"]["max"] * 1000.0 / line["steps"] - line["ms_per_step"]) < 1e-6 * line["ms_per_step"] + 1e-3
 
 
 def test_bench_one_rank_through_rccl():
@@ -90,6 +100,14 @@ def test_bench_single_rank_line_has_the_extra_verified_steps():
     ctr, dec = line["ctr_iteration_with_add_scalar"], line["configs4_decrypt_32_blocks"]
     assert ctr["verified_vs_aes"] is True and ctr["blocks_per_s"] > 0
     assert dec["verified_vs_aes"] is True and dec["blocks_per_s"] > 0 and dec["k2_launches"] == 19 and dec["k2_bits_per_launch"] == 32 * 128
+    two = line["two_contexts_64_blocks_each"]
+    assert two["verified_vs_aes"] is True and two["blocks_per_context"] == 16 and two["clone"]["path"] == "same_device" and two["clone"]["bytes"] > 0
+    assert "collective" not in line                                        # N = 1: nothing is broadcast between ranks
+    # the diagnostic identity of the roofline object: when a counter file of these sources is attached, ceiling x occupancy x clock / 2.4
+    # reproduces the profiled launch's own fraction (toy parameters: the fields are present and null)
+    r = line["roofline"]
+    if r["model_frac"] is not None:
+        assert abs(r["model_frac"] - r["frac_of_profiled_launch"]) <= 0.03 * r["frac_of_profiled_launch"]
 
 
 def test_bench_refuses_world_size_mismatch():

@@ -33,12 +33,43 @@ def test_cloned_context_holds_the_same_key_images_and_computes_the_same_words(to
     a.pfpks_batch(y, ga, 9)
     b.pfpks_batch(y, gb, 9)
     assert np.array_equal(ga, gb) and np.array_equal(ga, toy.oracle.pfpks(y))                        # K3 (PFPKSK image)
-    # cloning into a context with other parameters, or from one without keys, is an error, not a crash
+    info = b.clone_info()
+    assert info["path"] == "same_device" and info["bytes"] > 0 and info["seconds"] > 0     # both contexts on device 0: an HBM copy
+    assert a.clone_info()["path"] == "none"
+    # cloning from a context without keys is an error, not a crash
     c = _native.Engine(p, device=0)
-    with pytest.raises(_native.FheAesError):
+    with pytest.raises(_native.FheAesError) as e:
         b.clone_keys_from(c)
+    assert e.value.code == -2                                   # FHEAES_ERR_NOKEYS
     b.close()
     c.close()
+
+
+def test_clone_between_parameter_sets_is_refused(toy):
+    """the memcmp branch of fheaes_clone_keys: a context created for PARAM_OPT cannot take the toy keys"""
+    from tfhe_aes_amd import PARAM_OPT
+
+    other = _native.Engine(PARAM_OPT, device=0)
+    with pytest.raises(_native.FheAesError) as e:
+        other.clone_keys_from(toy.engine())
+    assert e.value.code == -1 and "parameter sets differ" in str(e.value)          # FHEAES_ERR_INVALID
+    other.close()
+
+
+def test_last_error_is_not_inherited_by_a_new_context(toy):
+    """the per-thread last-error cache is keyed by a context id, not by its address: a context created after a failed one was
+    destroyed (possibly at the same address) starts with an empty message"""
+    lib = _native.load_library()
+    p = toy.params
+    for _ in range(4):
+        bad = _native.Engine(p, device=0)
+        with pytest.raises(_native.FheAesError):
+            bad.keyswitch_batch(np.zeros((1, p.big1), dtype=np.uint64), np.zeros((1, p.n + 1), dtype=np.uint64), 1)   # no keys
+        assert b"keys" in lib.fheaes_last_error(bad._h)
+        bad.close()
+        fresh = _native.Engine(p, device=0)
+        assert lib.fheaes_last_error(fresh._h) == b""
+        fresh.close()
 
 
 def test_two_contexts_two_threads_equal_one_context(toy):
@@ -72,3 +103,41 @@ def test_two_contexts_two_threads_equal_one_context(toy):
     for t in ts:
         t.join()
     assert np.array_equal(outs[0], ref[0]) and np.array_equal(outs[1], ref[1])
+
+
+def test_two_contexts_at_param_opt_equal_one_context(opt):
+    """the in-process split at the reference's REAL parameter set on the one GPU there is: keys uploaded once (1.04 GB), cloned into a
+    second context (fheaes_clone_keys), 2 x 16 CTR blocks (Server::add_scalar + aes_encrypt, main.rs:59-61) from two host threads
+    == one context on all 32 blocks, word for word; the clone's path, size and time are what fheaes_clone_info reports"""
+    import time
+
+    from tfhe_aes_amd.aes_clear import aes128_encrypt_block
+
+    c, p = opt.client, opt.params
+    iv = 0xF0F1F2F3F4F5F6F7F8F9FAFBFCFDFEFF
+    n = 32
+    one = Server(opt.keys, device=0, engine=opt.engine())
+    rk = one.aes_key_expansion(c.encrypt_u128(c.key))
+    st = np.stack([c.encrypt_u128(iv)] * n)
+    ctrs = [0, 1, 0xFF, 0x100, 0x1FF] + list(range(5, n))
+    t0 = time.perf_counter()
+    want = one.aes_encrypt(rk, one.add_scalar(st.copy(), ctrs))
+    one.synchronize()
+    t_one = time.perf_counter() - t0
+    grp = ServerGroup(opt.keys, devices=(0, 0))
+    info = grp.clone_info()[0]
+    assert info["path"] == "same_device"
+    assert info["bytes"] == 66_060_288 + 635_699_200 + 342_528_000               # KSK + PFPKSK fragment planes (padded) + Fourier BSK (DESIGN.md 3)
+    t0 = time.perf_counter()
+    got = grp.aes_encrypt(rk, grp.add_scalar(st.copy(), ctrs))
+    t_two = time.perf_counter() - t0
+    assert np.array_equal(got, want)
+    for i in (0, 3, 4, n - 1):
+        assert c.decrypt_u128(got[i]) == aes128_encrypt_block(c.key, (iv + ctrs[i]) & ((1 << 128) - 1))
+    print("PARAM_OPT two contexts on one GPU: clone %.3f s for %.2f GB (%s); 32 blocks: one context %.2f s, two contexts x 16 blocks %.2f s"
+          % (info["seconds"], info["bytes"] / 1e9, info["path"], t_one, t_two))
+    with pytest.raises(ValueError):
+        grp.aes_encrypt(rk, st[0].copy())                                         # a single state must be wrapped, not cut into bytes
+    for s in grp.servers:
+        if s.engine is not opt.engine():
+            s.engine.close()

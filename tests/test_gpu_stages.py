@@ -166,3 +166,35 @@ def test_large_batches_are_chunked_consistently(toy):
     # spot-check against the oracle and the S-Box
     idx = [0, half - 1, half, n - 1]
     assert np.array_equal(whole[idx], toy.oracle.wopbs_batch(x[idx], luts))
+
+
+def test_param_opt_golden_hashes_on_gpu(opt, golden):
+    """the committed PARAM_OPT hashes (tests/golden/make_golden.py: oracle outputs on seeded inputs, generated in the build container)
+    against the HIP kernels on this box: K1 on 35 bits, K2 on 7, K3 on 3, K4, one many_sbox byte -- the oracle need not run here"""
+    from conftest import sha
+    from tfhe_aes_amd.client import Client
+
+    g = golden["oracle_opt"]
+    p, E = opt.params, opt.engine()
+    c = Client(1, opt.client.iv, opt.client.key, params=p, seed=g["seed"])           # fresh: same secret keys, encryption stream from 0
+    bits = np.array([int(ch) for ch in g["input_bits"]], dtype=np.uint8)
+    x = c.encrypt_bits(bits)
+    assert sha(x) == g["input"]
+    small = np.zeros((35, p.n + 1), dtype=np.uint64)
+    E.keyswitch_batch(x, small, 35)
+    assert sha(small) == g["keyswitch_35"]
+    pbs = np.zeros((7, p.big1), dtype=np.uint64)
+    E.cbs_pbs_batch(np.ascontiguousarray(small[:7]), pbs, 7)
+    assert sha(pbs) == g["cbs_pbs_7"] and [int(v) for v in pbs.reshape(-1)[:4]] == g["cbs_pbs_first_words"]
+    gg = np.zeros((3, p.k + 1, (p.k + 1) * 512), dtype=np.uint64)
+    E.pfpks_batch(np.ascontiguousarray(pbs[:3]), gg, 3)
+    assert sha(gg) == g["pfpks_3"]
+    polys = 3 * (p.k + 1) * (p.k + 1)
+    ff = np.zeros((polys, 256, 2), dtype=np.float64)
+    E.forward_fourier_batch(np.ascontiguousarray(gg.reshape(polys, 512)), ff, polys)
+    assert sha(ff) == g["ggsw_fourier_3"]
+    xb = c.encrypt_bytes([0x53])
+    assert sha(xb) == g["byte_input"]
+    y = np.zeros((1, 3, 8, p.big1), dtype=np.uint64)
+    E.many_sbox(xb, 1, False, y)
+    assert sha(y) == g["many_sbox_0x53"] and [int(v) for v in y.reshape(-1)[:4]] == g["many_sbox_first_words"]

@@ -27,10 +27,12 @@
 
 #define BRP_THREADS 512
 #ifndef BRP_EARLY
-#define BRP_EARLY 9          /* GGSW entries (of 15 per thread and level) requested between the instructions of the transform's second half */
+#define BRP_EARLY 9          /* GGSW entries (of 15 per thread and level) requested between the instructions of the transform's second half
+                                (6 / 8 / 9 / 10 / 12: 218.6 / 215.4 / 215.1 / 214.1 / 216.8 ms per 16,384-bit launch; 12 spills 4 registers) */
 #endif
 #ifndef BRP_TAIL
-#define BRP_TAIL 0           /* ... requested only after the multiply-accumulate has used row 0 */
+#define BRP_TAIL 4           /* ... requested only after the multiply-accumulate has used row 0, into the registers that row has left
+                                (0 / 2 / 3 / 4 / 5 / 6 on one box: 214.4 / 210.1 / 211.3 / 209.8 / 210.5 / 213.2 ms; on a slower one 220.4 / 218.8 for 0 / 4) */
 #endif
 #ifndef BRP_RESIDENT_HI
 #define BRP_RESIDENT_HI 1
@@ -39,8 +41,16 @@
 #define BRP_W1_LATE 2           /* 1: second half of the table column requested at the start of the twiddle pass; 2: in two requests of four entries, each
                                 into registers the first half has just left (no spill with hi[] resident: 249 VGPRs) */
 #endif
+#ifndef BRP_SPLIT_BARRIER
+#define BRP_SPLIT_BARRIER 0  /* measured: no gain (217.7 against 217.0-218.1 ms per 16,384-bit launch on one box): a wavefront waiting at the s_barrier
+                                leaves its SIMD to its partner of the other half, which is behind it anyway.  1 = the "tiles are free again" rendezvous before a level's first transpose store as ARRIVE (after a wavefront's last digit
+                                read of the previous level) + WAIT (before its first store), through a counter in LDS, instead of one s_barrier
+                                behind pass 1: a wavefront no longer waits for the others to REACH the same point of the program, only for them
+                                to have LEFT the multiply-accumulate -- which they did a decomposition step and a pass ago */
+#endif
 #define BRP_HALF_TILES (EP_GROUPS - 1)                                                   /* 15 tiles per half: group 15 shares group 14's */
 #define BRP_LDS_DOUBLES(R) (2 * FHE_TW_ENTRIES + 2 * BRP_HALF_TILES * GROUP_TILE_DOUBLES + ((R) == 3 ? 6 * FHE_N : 0))   /* R = 3: 159,488 B */
+#define BRP_SYNC_DOUBLES 2                                                               /* + the arrive counter of the split barrier */
 #define BRP_PARK_WORDS_PER_HALF (BRP_RESIDENT_HI ? 8 * EP_THREADS * 2 : 16 * EP_THREADS * 2)   /* per half and iteration: 32 KB (lo[] only) or 64 KB */
 
 __device__ __forceinline__ int brp_opaque_tid()
@@ -96,6 +106,49 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
     };
 
     ep_load_table(tw, A.tw);
+    // split barrier (BRP_SPLIT_BARRIER): one 32-bit arrive counter behind everything else in LDS; wait number n needs 8 n arrivals
+    unsigned *sync_word = reinterpret_cast<unsigned *>(lds_all + BRP_LDS_DOUBLES(3));
+    if (tid == 0) *sync_word = 0;
+    unsigned sync_target = 0;                                      // scalar
+    typedef __attribute__((address_space(3))) unsigned brp_lds_u32;
+    const unsigned sync_addr = (unsigned)(uintptr_t)(brp_lds_u32 *)sync_word;      // LDS byte address of the counter
+    auto arrive = [&]() {
+        // this wavefront's digit reads have returned; lane 0 adds one (EXEC narrowed inside the sequence: no branch for the compiler)
+        unsigned long long saved;
+        const unsigned one = 1;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     "s_mov_b64 %0, exec\n\t"
+                     "s_mov_b64 exec, 1\n\t"
+                     "ds_add_u32 %1, %2\n\t"
+                     "s_mov_b64 exec, %0\n\t"
+                     "s_waitcnt lgkmcnt(0)"                        /* the compiler's own wait counts know nothing of this LDS operation */
+                     : "=&s"(saved)
+                     : "v"(sync_addr), "v"(one)
+                     : "memory");
+    };
+    auto wait_arrivals = [&]() {
+        sync_target += BRP_THREADS / 64;
+        // The polling loop is ONE opaque instruction sequence (no control flow the register allocator has to reason about: written as
+        // a C loop it cost 60 spilled registers).  Bounded: every wavefront arrives without waiting for anybody (see level_body), so
+        // the count is reached; the bound (2^24 polls) only keeps a wrong build from spinning forever.
+        unsigned vtmp, stmp, scnt;
+        asm volatile("s_mov_b32 %2, 0\n"
+                     "1:\n\t"
+                     "ds_read_b32 %0, %3\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_readfirstlane_b32 %1, %0\n\t"
+                     "s_cmp_ge_u32 %1, %4\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "s_add_u32 %2, %2, 1\n\t"
+                     "s_cmp_lt_u32 %2, 0x1000000\n\t"
+                     "s_cbranch_scc0 2f\n\t"
+                     "s_sleep 1\n\t"
+                     "s_branch 1b\n"
+                     "2:"
+                     : "=&v"(vtmp), "=&s"(stmp), "=&s"(scnt)
+                     : "v"(sync_addr), "s"(sync_target)
+                     : "scc", "memory");
+    };
 
     uint64_t inst = inst0 + (uint64_t)hh * R + r_own;
     const bool valid = inst < A.count;
@@ -240,7 +293,11 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             EP_STAMP(2);
             constexpr int NE = BRP_EARLY, NHOOK = 7, NT = BRP_TAIL;
             auto early = [&](const int h) { key_rows(NE * h / NHOOK, NE * (h + 1) / NHOOK); };
+#if BRP_SPLIT_BARRIER
+            if (tiles_busy) wait_arrivals();                      // every wavefront of BOTH halves has left the previous level's multiply-accumulate
+#else
             if (tiles_busy) wg_barrier_lds_only();                // every thread of BOTH halves is done reading the previous level's digits
+#endif
             EP_STAMP(3);
             {
 #if FFT_XPOSE_PRIO
@@ -367,6 +424,9 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if BRP_SPLIT_BARRIER
+            if constexpr (!decltype(last)::value) arrive();       // this wavefront no longer reads the digit tiles of this level
+#endif
             EP_STAMP(7);
         };
 
@@ -497,7 +557,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 template <int K1, int LEVELS, int BASE_LOG, int R, int R2>
 __global__ __launch_bounds__(BRP_THREADS, 1) void blind_rotate_pair_kernel(const ExtProdArgs A)
 {
-    __shared__ __attribute__((aligned(16))) double lds_all[BRP_LDS_DOUBLES(R)];
+    __shared__ __attribute__((aligned(16))) double lds_all[BRP_LDS_DOUBLES(R) + BRP_SYNC_DOUBLES];
     if constexpr (R2 > 0) {
         if (blockIdx.x >= A.units_main) {       // scalar branch
             blind_rotate_pair_unit<K1, LEVELS, BASE_LOG, R2>(A, lds_all, (uint64_t)A.units_main * (2 * R) + (uint64_t)(blockIdx.x - A.units_main) * (2 * R2), blockIdx.x);

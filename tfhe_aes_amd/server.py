@@ -161,6 +161,10 @@ class ServerGroup:
 
         from .dist import shard_blocks
 
+        if state.ndim != 4:
+            # Server.aes_encrypt also takes ONE state [16][8][kN+1]; here the first axis is what gets sharded, so a single state would
+            # be cut into 16 "blocks" of one byte each: refuse it instead of computing nonsense
+            raise ValueError("ServerGroup works on a batch [n_blocks][16][8][kN+1]; wrap a single state as state[None]")
         n, g = int(state.shape[0]), len(self.servers)
         errs = [None] * g
 
@@ -196,3 +200,7 @@ class ServerGroup:
 
     def aes_key_expansion(self, key):
         return self.servers[0].aes_key_expansion(key)
+
+    def clone_info(self):
+        """per cloned context: how its keys got there ({"path": "same_device" | "peer" | "staged", "bytes", "seconds"})"""
+        return [s.engine.clone_info() for s in self.servers[1:]]

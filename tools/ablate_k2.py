@@ -28,6 +28,15 @@ VARIANTS = {
     "pair_e6": ["-DBRP_EARLY=6"], "pair_e12": ["-DBRP_EARLY=12"], "pair_w1": ["-DBRP_W1_LATE=0"], "pair_norh_w1": ["-DBRP_RESIDENT_HI=0", "-DBRP_W1_LATE=0"],
     "nopair_stamps": ["-DK2_PAIR=0", "-DEP_STAMPS"], "pair_w2": ["-DBRP_W1_LATE=2"], "pair_w2_e6": ["-DBRP_W1_LATE=2", "-DBRP_EARLY=6"], "pair_w2_e12": ["-DBRP_W1_LATE=2", "-DBRP_EARLY=12"],
     "pair_w2_stamps": ["-DBRP_W1_LATE=2", "-DEP_STAMPS"], "pair_w2_nopark": ["-DBRP_W1_LATE=2", "-DBR16_ABL_NOPARK"], "pair_w2_noload": ["-DBRP_W1_LATE=2", "-DBR16_ABL_NOLOAD"],
+    "pair_split": ["-DBRP_SPLIT_BARRIER=1"], "pair_e8": ["-DBRP_EARLY=8"], "pair_e10": ["-DBRP_EARLY=10"], "pair_e7_t3": ["-DBRP_EARLY=7", "-DBRP_TAIL=3"],
+    "pair_e9_t3": ["-DBRP_TAIL=3"], "pair_e10_t3": ["-DBRP_EARLY=10", "-DBRP_TAIL=3"], "pair_e9_t5": ["-DBRP_TAIL=5"], "pair_e9_t6": ["-DBRP_TAIL=6"], "pair_e8_t5": ["-DBRP_EARLY=8", "-DBRP_TAIL=5"],
+    "pair_e10_t5": ["-DBRP_EARLY=10", "-DBRP_TAIL=5"], "pair_e9_t3_pk16": ["-DBRP_TAIL=3", "-DBR16_PARK_AUX_ST=16"], "pair_e9_t3_c2": ["-DBRP_TAIL=3", "-DFFT_CHUNK=2"], "pair_e6_t6": ["-DBRP_EARLY=6", "-DBRP_TAIL=6"],
+    "pair_t4_c2": ["-DBRP_TAIL=4", "-DFFT_CHUNK=2"], "pair_t4_c1": ["-DBRP_TAIL=4", "-DFFT_CHUNK=1"], "pair_t4_c8": ["-DBRP_TAIL=4", "-DFFT_CHUNK=8"],
+    "pair_e10_t4": ["-DBRP_EARLY=10", "-DBRP_TAIL=4"], "pair_e11_t4": ["-DBRP_EARLY=11", "-DBRP_TAIL=4"], "pair_e8_t4": ["-DBRP_EARLY=8", "-DBRP_TAIL=4"],
+    "pair_t4_pk16": ["-DBRP_TAIL=4", "-DBR16_PARK_AUX_ST=16"], "pair_t4_nobar": ["-DBRP_TAIL=4", "-DFFT_CHUNK_BARRIERS=0"], "pair_t4_split": ["-DBRP_TAIL=4", "-DBRP_SPLIT_BARRIER=1"],
+    "pair_e9_t2": ["-DBRP_TAIL=2"], "pair_e9_t4": ["-DBRP_TAIL=4"], "pair_xprio0": ["-DFFT_XPOSE_PRIO=0"], "pair_pk00": ["-DBR16_PARK_AUX_LD=0"], "pair_pk16_2": ["-DBR16_PARK_AUX_ST=16"],
+    "pair_chunk2": ["-DFFT_CHUNK=2"], "pair_rot8": ["-DEP_ROT_CHUNK=8"],
+    "pair_nosplit": ["-DBRP_SPLIT_BARRIER=0"], "pair_nosplit_stamps": ["-DBRP_SPLIT_BARRIER=0", "-DEP_STAMPS"],
     "pair_nopark": ["-DBR16_ABL_NOPARK"], "pair_noload": ["-DBR16_ABL_NOLOAD"], "pair_stamps": ["-DEP_STAMPS"],
     "rh": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9"], "rh15": ["-DBR16_RESIDENT_HI=1"], "rh12": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=12"],
     "rh_t0": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9", "-DBR16_MAC_TAIL=0"], "rh_w1": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9", "-DBR16_W1_LATE=0"],

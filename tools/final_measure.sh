@@ -28,8 +28,9 @@ pmc sq SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_V
 pmc grbm GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum
 pmc act SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VMEM
 cd $R
+# 16,384 bits on 2,816 workgroups (2,560 of six ciphertexts, 256 of four): 5.8182 ciphertexts per workgroup on average
 python3 tools/summarize_pmc.py $O/pmc "blind_rotate_pair_kernel<5, 5" profiles/${ROUND}_pmc_blind_rotate 16384 --cus 256 --dyncount $O/k2_dyncount.txt \
-        --flops-per-ct-iteration 609280 --cts-per-wg 6 --waves-per-wg 8 --algorithmic-bytes 698912768 > $O/pmc_summary.txt
+        --flops-per-ct-iteration 609280 --cts-per-wg 5.8182 --waves-per-wg 8 --algorithmic-bytes 698912768 > $O/pmc_summary.txt
 cp profiles/${ROUND}_pmc_blind_rotate.json $O/
 cd /tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
