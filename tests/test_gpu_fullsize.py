@@ -120,12 +120,26 @@ def test_1024_ctr_blocks_on_one_gpu(opt, opt_server):
 
 
 def test_k2_launch_forms_agree_at_full_size(opt):
-    """BASELINE configs[2] launches 16,384 bits of blind rotation at a time: 5,120 three-ciphertext + 512 two-ciphertext workgroups in
-    one kernel (fheaes_k2_launch_plan).  The oracle would need minutes for that batch; the size-independent property is that
-    the cut of a batch into launches and workgroups does not change a single word: the same rows in 1,024-bit launches
-    (342 three-ciphertext workgroups, no tail), in a 4,096-bit launch (1,024 + 512), and -- for the first 256 rows -- in the latency
-    form (one ciphertext per 512-thread workgroup) give identical outputs."""
+    """BASELINE configs[2] launches 16,384 bits of blind rotation at a time: 2,560 six-ciphertext + 256 four-ciphertext workgroups of the
+    paired kernel (kern_blindrot_pair.h; fheaes_k2_launch_plan form 2).  The oracle would need minutes for that batch; the size-independent
+    property is that neither the cut of a batch into launches and workgroups NOR THE KERNEL that runs it changes a single word: the same
+    rows in 1,024-bit launches (256 four-ciphertext paired units), in a 4,096-bit launch (512 six + 256 four), in 768-bit launches -- which
+    take the OTHER throughput kernel (kern_blindrot16.h: three ciphertexts per 256-thread workgroup, written a round earlier, compared
+    with the oracle up to 520 bits in test_gpu_stages.py) -- and, for the first 256 rows, in the latency form (one ciphertext per
+    512-thread workgroup) give identical outputs."""
+    import ctypes as C
+
     import torch
+
+    from tfhe_aes_amd import _native
+
+    lib = _native.load_library()
+    def form(m):
+        f, um, ut = C.c_int(), C.c_uint64(), C.c_uint64()
+        rm, rt = C.c_uint32(), C.c_uint32()
+        assert lib.fheaes_k2_launch_plan(m, 256, 4, C.byref(f), C.byref(um), C.byref(rm), C.byref(ut), C.byref(rt)) == 0
+        return f.value
+    assert (form(16384), form(4096), form(1024), form(768), form(256)) == (2, 2, 2, 1, 0)     # which kernel each cut below runs
 
     p, E = opt.params, opt.engine()
     rng = np.random.default_rng(16384)
@@ -137,6 +151,12 @@ def test_k2_launch_forms_agree_at_full_size(opt):
     part = torch.empty_like(full)
     for lo in range(0, m, 1024):
         E.cbs_pbs_batch(small[lo:lo + 1024], part[lo:lo + 1024], 1024)
+    E.synchronize()
+    assert torch.equal(full, part)
+    part.zero_()
+    for lo in range(0, m, 768):                                     # the whole batch again through the 16-form kernel
+        n = min(768, m - lo)
+        E.cbs_pbs_batch(small[lo:lo + n], part[lo:lo + n], n)
     E.synchronize()
     assert torch.equal(full, part)
     mid = torch.empty((4096, p.big1), dtype=torch.int64, device="cuda")
