@@ -60,7 +60,7 @@ __device__ __forceinline__ void cmulc(double &xr, double &xi, double wr, double 
 // DFT of length 16 in registers, radix-2 decimation in time, natural order in and out.
 // INV = false: kernel e^{+2 pi i a (k + phi)/16}, phi = OFFSET ? 1/4 : 0; INV = true: conjugate kernel (phi = 0 only).
 // `hook(stage)` runs after butterfly stage 0..3 (a caller interleaves independent memory instructions there);
-// `chunk_hook(stage, c0)` after every chunk of butterflies c0 .. c0+FFT_CHUNK-1 of a stage: in the LAST stage (3) butterfly k
+// `chunk_hook(stage, c0)` after every chunk of butterflies c0 .. c0+CHUNK-1 of a stage (CHUNK: template parameter, default FFT_CHUNK): in the LAST stage (3) butterfly k
 // has just produced the final outputs k and k + 8, which live in registers fft_reg(k), fft_reg(k + 8) until dft16 returns
 // (natural order only after the renaming at its end) -- a caller can store them while the rest of the stage computes.
 struct FftNoHook { __device__ __forceinline__ void operator()(int) const {} };
@@ -69,9 +69,10 @@ __device__ __forceinline__ constexpr int fft_reg(int k)       // register that h
 {
     return ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);
 }
-template <bool INV, bool OFFSET, typename Hook = FftNoHook, typename ChunkHook = FftNoChunkHook>
+template <bool INV, bool OFFSET, int CHUNK = FFT_CHUNK, typename Hook = FftNoHook, typename ChunkHook = FftNoChunkHook>
 __device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], Hook hook = Hook(), ChunkHook chunk_hook = ChunkHook())
 {
+    static_assert(CHUNK == 1 || CHUNK == 2 || CHUNK == 4 || CHUNK == 8, "butterflies per chunk");
     static_assert(!(INV && OFFSET), "the inverse applies its untwist after the transform");
     constexpr int BR[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};   // logical position -> register
 #pragma unroll
@@ -81,10 +82,10 @@ __device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], Hook h
         // then every v): a dependent f64 instruction issues 8 cycles after its producer, and a wave that has the SIMD to itself
         // (the other one waiting for memory) would otherwise stand still for half of that behind every fused pair.
 #pragma unroll
-        for (int c0 = 0; c0 < 8; c0 += FFT_CHUNK) {
-            double tr[FFT_CHUNK], ti[FFT_CHUNK];
+        for (int c0 = 0; c0 < 8; c0 += CHUNK) {
+            double tr[CHUNK], ti[CHUNK];
 #pragma unroll
-            for (int j = 0; j < FFT_CHUNK; ++j) {
+            for (int j = 0; j < CHUNK; ++j) {
                 const int i = c0 + j, blk = (i / half) * n, k = i % half;
                 const int e = OFFSET ? (64 * k + 16) / n : 64 * k / n;      // twiddle psi^(16 e), e in 0..31
                 const int P = BR[blk + k], Q = BR[blk + k + half];
@@ -96,7 +97,7 @@ __device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], Hook h
             }
             if (FFT_CHUNK_BARRIERS) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < FFT_CHUNK; ++j) {
+            for (int j = 0; j < CHUNK; ++j) {
                 const int i = c0 + j, blk = (i / half) * n, k = i % half;
                 const int e = OFFSET ? (64 * k + 16) / n : 64 * k / n;
                 const int Q = BR[blk + k + half];
@@ -108,7 +109,7 @@ __device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], Hook h
             }
             if (FFT_CHUNK_BARRIERS) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < FFT_CHUNK; ++j) {
+            for (int j = 0; j < CHUNK; ++j) {
                 const int i = c0 + j, blk = (i / half) * n, k = i % half;
                 const int e = OFFSET ? (64 * k + 16) / n : 64 * k / n;
                 const int P = BR[blk + k], Q = BR[blk + k + half];

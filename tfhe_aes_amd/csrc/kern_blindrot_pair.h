@@ -41,6 +41,12 @@
 #define BRP_W1_LATE 2           /* 1: second half of the table column requested at the start of the twiddle pass; 2: in two requests of four entries, each
                                 into registers the first half has just left (no spill with hi[] resident: 249 VGPRs) */
 #endif
+#ifndef BRP_MAC_PRIO
+#define BRP_MAC_PRIO 1       /* wave priority during the multiply-accumulate (0 / 1 / 3: 214.2 / 211.8 / 212.0 ms per 16,384-bit launch) */
+#endif
+#ifndef BRP_CHUNK
+#define BRP_CHUNK 1          /* butterflies issued together in this kernel's transforms (fft_dev.h dft16; 1 / 2 / 4 / 8: 211.5 / 214.4 / 214.2 / 223.4 ms) */
+#endif
 #ifndef BRP_SPLIT_BARRIER
 #define BRP_SPLIT_BARRIER 0  /* measured: no gain (217.7 against 217.0-218.1 ms per 16,384-bit launch on one box): a wavefront waiting at the s_barrier
                                 leaves its SIMD to its partner of the other half, which is behind it anyway.  1 = the "tiles are free again" rendezvous before a level's first transpose store as ARRIVE (after a wavefront's last digit
@@ -288,7 +294,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            dft16<false, true>(xr, xi);
+            dft16<false, true, BRP_CHUNK>(xr, xi);
             __builtin_amdgcn_sched_barrier(0);
             EP_STAMP(2);
             constexpr int NE = BRP_EARLY, NHOOK = 7, NT = BRP_TAIL;
@@ -334,12 +340,12 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 #if FFT_XPOSE_PRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
-                dft16<false, false>(xr, xi, [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } },
+                dft16<false, false, BRP_CHUNK>(xr, xi, [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } },
                                     [&](const int stage, const int c0) {
                                         if (stage != 3) return;
                                         if (c0 == 0) wave_lds_sync();
 #pragma unroll
-                                        for (int j = 0; j < FFT_CHUNK; ++j) {
+                                        for (int j = 0; j < BRP_CHUNK; ++j) {
 #pragma unroll
                                             for (int h = 0; h < 2; ++h) {
                                                 const int k2 = c0 + j + 8 * h;
@@ -349,8 +355,8 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                                         }
                                         __builtin_amdgcn_sched_barrier(0);
                                         {
-                                            constexpr int NL = NQ - NE - NT, PARTS = 8 / FFT_CHUNK;
-                                            const int part = c0 / FFT_CHUNK;
+                                            constexpr int NL = NQ - NE - NT, PARTS = 8 / BRP_CHUNK;
+                                            const int part = c0 / BRP_CHUNK;
                                             key_rows(NE + NL * part / PARTS, NE + NL * (part + 1) / PARTS);
                                         }
                                     });
@@ -362,6 +368,9 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             EP_STAMP(6);
             // ---- multiply-accumulate: thread (hh, tq) owns Fourier point tq; digits of row p for the RT ciphertexts, one row ahead ----
             // local ciphertext r': r' < R in this half's tiles, r' >= R in the other half's (tile (r' mod R) * K1 + p of that half)
+#if BRP_MAC_PRIO
+            __builtin_amdgcn_s_setprio(BRP_MAC_PRIO);
+#endif
             const double *own = ldsh + 2 * tq, *oth = ldso + 2 * tq;
             double2 dn[RT];
 #pragma unroll
@@ -424,6 +433,9 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+#if BRP_MAC_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
 #if BRP_SPLIT_BARRIER
             if constexpr (!decltype(last)::value) arrive();       // this wavefront no longer reads the digit tiles of this level
 #endif
@@ -477,7 +489,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
         fft_inv_table(w0, w1, tw, bq_);
         wave_lds_sync();
         EP_STAMP(8);
-        dft16<true, false>(xr, xi);
+        dft16<true, false, BRP_CHUNK>(xr, xi);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
@@ -503,7 +515,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             for (int a = 0; a < 16; ++a) { pk[a].x = home[16 * a + bq_]; pk[a].y = home[256 + 16 * a + bq_]; }
 #endif
         }
-        dft16<true, false>(xr, xi);
+        dft16<true, false, BRP_CHUNK>(xr, xi);
 #pragma unroll
         for (int a = 1; a < 16; ++a) cmulc(xr[a], xi[a], FHE_PSI16_RE[a], FHE_PSI16_IM[a]);
         EP_STAMP(9);
