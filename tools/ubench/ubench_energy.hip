@@ -5,6 +5,7 @@
 // Each mode runs ~1.5 s on all 256 CUs with 8 waves per CU and reads the socket energy counter (rocm_smi) around it:
 //   idle      nothing (static power)
 //   fma       v_fma_f64 back to back (4 independent chains per lane)
+//   mfma i8   v_mfma_i32_16x16x64_i8 back to back on pseudo-random bytes (8 accumulators per wave)
 //   lds       ds_read_b128 from a conflict-free 16 KB window
 //   l1        buffer_load_dwordx4 of the same 8 KB per wave again and again (L1 hits)
 //   l2        every workgroup walks the same 2 MB (L2 hits after the first touch; the blind rotation's key rows)
@@ -42,6 +43,25 @@ __global__ __launch_bounds__(512, 1) void k_fma(double *sink, int iters)
         }
     }
     sink[blockIdx.x * 512 + threadIdx.x] = a0 + a1 + a2 + a3;
+}
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// int8 matrix cores: v_mfma_i32_16x16x64_i8, 8 independent accumulators per wave, operand bytes pseudo-random and lane-dependent
+// (the key-switching kernels K1 / K3 multiply balanced random bytes: all-zero operands would make the array look cheaper than it is)
+__global__ __launch_bounds__(512, 1) void k_mfma_i8(int *sink, int iters)
+{
+    i32x4 a[2], b[4], acc[8];
+    unsigned x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) { x = x * 1664525u + 1013904223u; a[i][j] = (int)x; }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { x = x * 1664525u + 1013904223u; b[i][j] = (int)x; }
+    for (int i = 0; i < 8; ++i) acc[i] = (i32x4){0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[u & 1], b[u & 3], acc[u], 0, 0, 0);
+    }
+    int r = 0;
+    for (int i = 0; i < 8; ++i) r += acc[i][0] + acc[i][3];
+    sink[blockIdx.x * 512 + threadIdx.x] = r;
 }
 
 __global__ __launch_bounds__(512, 1) void k_lds(double *sink, int iters)
@@ -142,6 +162,11 @@ int main()
         double n = 0; const int it = 40000;
         Res r = timed([&] { hipLaunchKernelGGL(k_fma, dim3(G), dim3(512), 0, 0, sink, it); n += (double)G * 512 * it * 64 * 2; });
         report("fma", r, n, "flop");
+    }
+    {
+        double n = 0; const int it = 40000;            // per wave-instruction 16 x 16 x 64 = 16,384 multiply-adds
+        Res r = timed([&] { hipLaunchKernelGGL(k_mfma_i8, dim3(G), dim3(512), 0, 0, reinterpret_cast<int *>(sink), it); n += (double)G * 8 * it * 8 * 16384.0; });
+        report("mfma i8", r, n, "MAC");
     }
     {
         double n = 0; const int it = 100000;
