@@ -212,6 +212,7 @@ struct fheaes_ctx {
     // layers count how many nominal-noise ciphertexts (fresh WoPBS outputs, round keys, client encryptions) they sum into one
     uint32_t noise_level_seen = 0;
     int k2_home = -1;                    // blind rotation: 1 = the LDS-home form runs two workgroups per CU here (queried once), 0 = parked form
+    int k2_pair_ok = -1;                 // 1 = the paired kernel (159,504 B of LDS per workgroup) can be resident on a CU here (queried once)
     // keys
     int8_t *ksk_frag = nullptr, *pfpksk_frag = nullptr;      // balanced key bytes in MFMA B-fragment order
     uint32_t ks_ksteps = 0, ks_coltiles = 0, pf_ksteps = 0, pf_coltiles = 0;
@@ -380,11 +381,11 @@ struct StampReport {
 #define K2_PAIR_MIN_BITS 768ull
 #endif
 struct K2Plan { int form; uint64_t units_main; uint32_t r_main; uint64_t units_tail; uint32_t r_tail; };
-K2Plan k2_plan(uint64_t m, uint32_t cu_count, uint32_t k1)
+K2Plan k2_plan(uint64_t m, uint32_t cu_count, uint32_t k1, bool allow_pair = true)
 {
     K2Plan pl{};
     if (m <= LATENCY_BATCH_BITS) { pl.form = 0; pl.units_main = m; pl.r_main = 1; return pl; }
-    if (K2_PAIR && k1 == 5 && m > K2_PAIR_MIN_BITS) {
+    if (K2_PAIR && allow_pair && k1 == 5 && m > K2_PAIR_MIN_BITS) {
         // paired form: units of 6 and of 4 ciphertexts, one workgroup per CU, a whole number of generations that covers the batch
         // (16,384 bits = 2,560 x 6 + 256 x 4 = 11 generations; 4,096 = 512 x 6 + 256 x 4 = 3; 1,152 = 64 x 6 + 192 x 4 = 1); the
         // smaller units last
@@ -480,6 +481,19 @@ int launch_forward_fourier(fheaes_ctx *c, const uint64_t *in, uint64_t polys, do
     return FHEAES_OK;
 }
 
+// the paired kernel takes nearly all of a CU's LDS: where the runtime cannot place even one such workgroup (a driver that reserves LDS)
+// every batch falls back to the 16-form instead of failing the launch
+bool k2_pair_allowed(fheaes_ctx *c)
+{
+    if (c->k2_pair_ok < 0) {
+        int per_cu = 0;
+        const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blind_rotate_pair_kernel<5, 5, 8, 3, 2>, BRP_THREADS, 0);
+        c->k2_pair_ok = (oe == hipSuccess && per_cu >= 1) ? 1 : 0;
+        (void)hipGetLastError();
+    }
+    return c->k2_pair_ok == 1;
+}
+
 int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_t level, uint64_t *out)
 {
     if (m == 0) return FHEAES_OK;
@@ -504,7 +518,7 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         else hipLaunchKernelGGL((blind_rotate_latency_kernel<2, 5, 8>), dim3((unsigned)m), dim3(BL_THREADS), 0, c->stream, a);
         // (257..768 bits: the throughput form below with at most one workgroup per CU, 14.6 ms per launch; the round-1
         //  one-ciphertext-per-workgroup form of kern_extprod.h took 21.6 ms there and the latency form in two waves 16-18 ms)
-    } else if (k2_plan(m, c->cu_count, c->k1).form == 2) {
+    } else if (k2_plan(m, c->cu_count, c->k1, k2_pair_allowed(c)).form == 2) {
         // paired throughput form (kern_blindrot_pair.h): one 512-thread workgroup per CU, 6 (or 4) ciphertexts share every key fetch
         const K2Plan pl = k2_plan(m, c->cu_count, c->k1);
         const unsigned gridp = (unsigned)(pl.units_main + pl.units_tail);
@@ -522,7 +536,7 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         hipLaunchKernelGGL((blind_rotate_pair_kernel<5, 5, 8, 3, 2>), dim3(gridp), dim3(BRP_THREADS), 0, c->stream, a);
     } else {
         // throughput form (kern_blindrot16.h): accumulator parked in HBM between uses, key rows prefetched across the transform
-        const K2Plan pl = k2_plan(m, c->cu_count, c->k1);
+        const K2Plan pl = k2_plan(m, c->cu_count, c->k1, false);
         const unsigned grid16 = (unsigned)(pl.units_main + pl.units_tail);
         a.units_main = (uint32_t)pl.units_main;
         const size_t park_bytes = (size_t)grid16 * BR16_PARK_WORDS_PER_WG * 8;
@@ -883,7 +897,7 @@ int fheaes_reserve(fheaes_ctx *c, uint64_t max_bits)
     TRY(ensure(c, c->ws_ggswf, bits * ggsw_words * 8));
     {
         // the blind rotation's parking slab for the largest launch this reservation covers (64 KB per workgroup)
-        const K2Plan pl = k2_plan(bits, c->cu_count, c->k1);
+        const K2Plan pl = k2_plan(bits, c->cu_count, c->k1, k2_pair_allowed(c));
         if (pl.form == 1) TRY(ensure(c, c->ws_park, (size_t)(pl.units_main + pl.units_tail) * BR16_PARK_WORDS_PER_WG * 8));
         if (pl.form == 2) TRY(ensure(c, c->ws_park, (size_t)(pl.units_main + pl.units_tail) * 2 * BRP_PARK_WORDS_PER_HALF * 8));
     }
