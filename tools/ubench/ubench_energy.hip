@@ -30,8 +30,12 @@ static double energy_j()
     return (double)e * res * 1e-6;
 }
 
+// MASKED: lanes 16..63 of every wave leave at once, so the same instruction stream runs with a quarter of EXEC set: what does an
+// inactive lane cost? (the question behind "switch the idle lane groups of the blind rotation off")
+template <bool MASKED>
 __global__ __launch_bounds__(512, 1) void k_fma(double *sink, int iters)
 {
+    if (MASKED && (threadIdx.x & 63) >= 16) return;
     double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3; const double m = 1.0000001, c = 1e-9;
     for (int i = 0; i < iters; ++i) {
 #pragma unroll
@@ -160,8 +164,13 @@ int main()
     };
     {
         double n = 0; const int it = 40000;
-        Res r = timed([&] { hipLaunchKernelGGL(k_fma, dim3(G), dim3(512), 0, 0, sink, it); n += (double)G * 512 * it * 64 * 2; });
+        Res r = timed([&] { hipLaunchKernelGGL(k_fma<false>, dim3(G), dim3(512), 0, 0, sink, it); n += (double)G * 512 * it * 64 * 2; });
         report("fma", r, n, "flop");
+    }
+    {
+        double n = 0; const int it = 40000;            // a quarter of the lanes active: flops counted for the active lanes only
+        Res r = timed([&] { hipLaunchKernelGGL(k_fma<true>, dim3(G), dim3(512), 0, 0, sink, it); n += (double)G * 128 * it * 64 * 2; });
+        report("fma 1/4", r, n, "flop");
     }
     {
         double n = 0; const int it = 40000;            // per wave-instruction 16 x 16 x 64 = 16,384 multiply-adds
