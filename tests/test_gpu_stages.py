@@ -38,13 +38,13 @@ def test_k1_keyswitch(which, m, request):
 
 
 @pytest.mark.parametrize("which,m", [("toy", 1), ("toy", 8), ("toy", 21), ("toy", 300), ("toy", 530),
-                                     ("opt", 1), ("opt", 7), ("opt", 300), ("opt", 520), ("opt", 800), ("opt", 2100)])
+                                     ("opt", 1), ("opt", 7), ("opt", 300), ("opt", 520), ("opt", 800), ("opt", 1001), ("opt", 2100)])
 def test_k2_blind_rotation(which, m, request):
     # every launch form of engine.hip::launch_cbs_pbs: m <= 256 the one-ciphertext-per-512-thread-workgroup latency kernel
     # (1, 7/8/21 bits: every sharing degree of its L2 walk); up to 768 bits kern_blindrot16.h with 3 (k=4) or 8 (k=1) ciphertexts per
     # 256-thread workgroup, at most one per CU (opt 300 in two-ciphertext units, 520 in three-ciphertext ones, ragged last one; the toy
     # set always); beyond that, at k=4, the paired kernel kern_blindrot_pair.h: opt 800 = 200 four-ciphertext 512-thread units, opt
-    # 2100 = two full generations of 26 six- and 486 four-ciphertext units (both unit bodies, the home wavefronts, the mirrored groups)
+    # 1001 = 251 of them with a ragged last one (three of its four slots empty), opt 2100 = two full generations of 26 six- and 486 four-ciphertext units (both unit bodies, the home wavefronts, the mirrored groups)
     kit = request.getfixturevalue(which)
     p, E = kit.params, kit.engine()
     x, bits = _inputs(kit, m, 20 + m)
