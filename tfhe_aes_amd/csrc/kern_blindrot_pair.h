@@ -54,9 +54,17 @@
                                 behind pass 1: a wavefront no longer waits for the others to REACH the same point of the program, only for them
                                 to have LEFT the multiply-accumulate -- which they did a decomposition step and a pass ago */
 #endif
+#ifndef BRP_MASK_IDLE
+#define BRP_MASK_IDLE 0      /* 1: the lane groups that own no polynomial are switched off wherever the program neither writes a tile another
+                                group reads nor requests a key row for their multiply-accumulate role (rotation, decomposition, pass 1, inverse
+                                transform, conversion): EXEC is narrowed by hand around those stretches (as `if (owner)` regions the register
+                                allocator spilled 1,061 registers).  Group 15 of a half is then no mirror of group 14: it gets a scratch tile */
+#endif
 #define BRP_HALF_TILES (EP_GROUPS - 1)                                                   /* 15 tiles per half: group 15 shares group 14's */
 #define BRP_LDS_DOUBLES(R) (2 * FHE_TW_ENTRIES + 2 * BRP_HALF_TILES * GROUP_TILE_DOUBLES + ((R) == 3 ? 6 * FHE_N : 0))   /* R = 3: 159,488 B */
-#define BRP_SYNC_DOUBLES 2                                                               /* + the arrive counter of the split barrier */
+#define BRP_SYNC_DOUBLES (BRP_SPLIT_BARRIER ? 2 : 0)                                     /* + the arrive counter of the split barrier */
+#define BRP_SCRATCH_DOUBLES (BRP_MASK_IDLE ? GROUP_TILE_DOUBLES : 0)                     /* + the scratch tile of the two switched-off groups 15 */
+static_assert(!(BRP_SPLIT_BARRIER && BRP_MASK_IDLE), "the scratch tile takes the LDS the arrive counter would need");
 #define BRP_PARK_WORDS_PER_HALF (BRP_RESIDENT_HI ? 8 * EP_THREADS * 2 : 16 * EP_THREADS * 2)   /* per half and iteration: 32 KB (lo[] only) or 64 KB */
 
 __device__ __forceinline__ int brp_opaque_tid()
@@ -90,13 +98,28 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
     const bool home_wave = HOME && __builtin_amdgcn_readfirstlane(tq0) >= 16 * HOME_G0;
     double *ldsh = lds + hh * (BRP_HALF_TILES * GROUP_TILE_DOUBLES);                      // this half's tiles (scalar)
     double *ldso = lds + (1 - hh) * (BRP_HALF_TILES * GROUP_TILE_DOUBLES);                // the other half's
+    // MASK: group 15 of either half works in the scratch tile behind the homes (nobody reads it)
+    double *scratch = lds_all + BRP_LDS_DOUBLES(3) + BRP_SYNC_DOUBLES;
+    // wave-uniform: the lanes of this wavefront whose group owns a polynomial; mask_on() narrows EXEC to them, mask_off() restores it.
+    // Done with opaque scalar moves: the compiler sees straight-line code (every value it computes inside such a stretch is consumed
+    // by the owners' work only: lane indices are re-derived per phase from brp_opaque_tid()).
+    const unsigned long long own_mask = __builtin_amdgcn_ballot_w64(g < R * K1);
+    unsigned long long exec_saved = 0;
+    auto mask_on = [&]() {
+        if (BRP_MASK_IDLE) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1" : "=&s"(exec_saved) : "s"(own_mask) : "memory", "scc"); __builtin_amdgcn_sched_barrier(0); }
+    };
+    auto mask_off = [&]() {
+        if (BRP_MASK_IDLE) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_mov_b64 exec, %0" :: "s"(exec_saved) : "memory"); __builtin_amdgcn_sched_barrier(0); }
+    };
     auto tile_of = [&](const int tq) -> double * {
         int gq = tq >> 4;
+        if (BRP_MASK_IDLE) return gq <= LAST_T ? ldsh + gq * GROUP_TILE_DOUBLES : scratch;
         gq = gq < LAST_T ? gq : LAST_T;
         return ldsh + gq * GROUP_TILE_DOUBLES;
     };
     auto stage_of = [&](const int tq) -> uint64_t * {
         int gq = tq >> 4;
+        if (BRP_MASK_IDLE && gq > LAST_T) return reinterpret_cast<uint64_t *>(scratch);
         gq = gq < LAST_T ? gq : LAST_T;
         if (HOME) {
             const int tile_words = hh * (BRP_HALF_TILES * GROUP_TILE_DOUBLES) + gq * GROUP_TILE_DOUBLES;
@@ -211,11 +234,13 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
         }
 #endif
     };
+    mask_on();
     {
         const int tq = brp_opaque_tid() & 255;
 #pragma unroll
         for (int a = 0; a < 16; ++a) stage_park(a, tq);
     }
+    mask_off();
     for (uint32_t it = 0; it < A.iters; ++it) {
         const int t = mod_switch_1024(a_next);
         a_next = lwe[it + 1];
@@ -226,6 +251,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
         double xr[16], xi[16];
         double2 w0[8], w1[8];
         EP_STAMP(11);
+        mask_on();
         {
             const int tq = brp_opaque_tid() & 255;
             const int bq_ = tq & 15;
@@ -252,6 +278,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             }
             wave_lds_sync();
         }
+        mask_off();
         EP_STAMP(0);
 
         // sums: local ciphertext r' = 0..RT-1 is ciphertext (r' + R hh) mod RT of the unit, so r' < R are this half's own;
@@ -294,7 +321,9 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE);
 #endif
             __builtin_amdgcn_sched_barrier(0);
+            mask_on();
             dft16<false, true, BRP_CHUNK>(xr, xi);
+            mask_off();
             __builtin_amdgcn_sched_barrier(0);
             EP_STAMP(2);
             constexpr int NE = BRP_EARLY, NHOOK = 7, NT = BRP_TAIL;
@@ -445,6 +474,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 #pragma unroll 1
         for (int l = LEVELS - 1; l >= 1; --l) {
             level_body(l, l != LEVELS - 1, std::false_type{});
+            mask_on();
             {
                 const int tq = brp_opaque_tid() & 255;
                 fft_tw_load8(w0, tw, tq & 15, FHE_TW_STRIDE);
@@ -455,6 +485,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                 xr[a] = (double)decompose_next<BASE_LOG>(st_lo[a]);
                 xi[a] = (double)decompose_next<BASE_LOG>(st_hi[a]);
             }
+            mask_off();
             EP_STAMP(1);
         }
         level_body(0, LEVELS > 1, std::true_type{});
@@ -481,6 +512,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             }
         }
         wg_barrier_lds_only();
+        mask_on();
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
             double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ + 16 * k2));
@@ -532,6 +564,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             stage_park(a, tq);
             if ((a & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
+        mask_off();
         EP_STAMP(10);
     }
 #ifdef EP_STAMPS
@@ -569,7 +602,8 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 template <int K1, int LEVELS, int BASE_LOG, int R, int R2>
 __global__ __launch_bounds__(BRP_THREADS, 1) void blind_rotate_pair_kernel(const ExtProdArgs A)
 {
-    __shared__ __attribute__((aligned(16))) double lds_all[BRP_LDS_DOUBLES(R) + BRP_SYNC_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double lds_all[BRP_LDS_DOUBLES(R) + BRP_SYNC_DOUBLES + BRP_SCRATCH_DOUBLES];
+    static_assert((BRP_LDS_DOUBLES(R) + BRP_SYNC_DOUBLES + BRP_SCRATCH_DOUBLES) * 8 <= 163840, "one workgroup must fit the 160 KB of a CU");
     if constexpr (R2 > 0) {
         if (blockIdx.x >= A.units_main) {       // scalar branch
             blind_rotate_pair_unit<K1, LEVELS, BASE_LOG, R2>(A, lds_all, (uint64_t)A.units_main * (2 * R) + (uint64_t)(blockIdx.x - A.units_main) * (2 * R2), blockIdx.x);

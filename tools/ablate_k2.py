@@ -34,6 +34,7 @@ VARIANTS = {
     "pair_t4_c2": ["-DBRP_TAIL=4", "-DFFT_CHUNK=2"], "pair_t4_c1": ["-DBRP_TAIL=4", "-DFFT_CHUNK=1"], "pair_t4_c8": ["-DBRP_TAIL=4", "-DFFT_CHUNK=8"],
     "pair_e10_t4": ["-DBRP_EARLY=10", "-DBRP_TAIL=4"], "pair_e11_t4": ["-DBRP_EARLY=11", "-DBRP_TAIL=4"], "pair_e8_t4": ["-DBRP_EARLY=8", "-DBRP_TAIL=4"],
     "pair_t4_pk16": ["-DBRP_TAIL=4", "-DBR16_PARK_AUX_ST=16"], "pair_t4_nobar": ["-DBRP_TAIL=4", "-DFFT_CHUNK_BARRIERS=0"], "pair_t4_split": ["-DBRP_TAIL=4", "-DBRP_SPLIT_BARRIER=1"],
+    "pair_mask": ["-DBRP_MASK_IDLE=1"],
     "pair_mp0": ["-DBRP_MAC_PRIO=0"], "pair_bc4": ["-DBRP_CHUNK=4"], "pair_bc2": ["-DBRP_CHUNK=2"], "pair_mp0_bc4": ["-DBRP_MAC_PRIO=0", "-DBRP_CHUNK=4"], "pair_mp2": ["-DBRP_MAC_PRIO=2"],
     "pair_xprio1": ["-DFFT_XPOSE_PRIO=1"], "pair_xprio3": ["-DFFT_XPOSE_PRIO=3"], "pair_macprio1": ["-DBRP_MAC_PRIO=1"], "pair_macprio3": ["-DBRP_MAC_PRIO=3"],
     "pair_c2": ["-DFFT_CHUNK=2"], "pair_c1": ["-DFFT_CHUNK=1"],
