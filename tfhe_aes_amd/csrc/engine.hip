@@ -212,7 +212,7 @@ struct fheaes_ctx {
     // layers count how many nominal-noise ciphertexts (fresh WoPBS outputs, round keys, client encryptions) they sum into one
     uint32_t noise_level_seen = 0;
     int k2_home = -1;                    // blind rotation: 1 = the LDS-home form runs two workgroups per CU here (queried once), 0 = parked form
-    int k2_pair_ok = -1;                 // 1 = the paired kernel (159,504 B of LDS per workgroup) can be resident on a CU here (queried once)
+    int k2_pair_ok = -1;                 // 1 = the paired kernel (159,488 B of LDS per workgroup) can be resident on a CU here (queried once)
     // keys
     int8_t *ksk_frag = nullptr, *pfpksk_frag = nullptr;      // balanced key bytes in MFMA B-fragment order
     uint32_t ks_ksteps = 0, ks_coltiles = 0, pf_ksteps = 0, pf_coltiles = 0;

@@ -47,24 +47,20 @@
 #ifndef BRP_CHUNK
 #define BRP_CHUNK 1          /* butterflies issued together in this kernel's transforms (fft_dev.h dft16; 1 / 2 / 4 / 8: 211.5 / 214.4 / 214.2 / 223.4 ms) */
 #endif
-#ifndef BRP_SPLIT_BARRIER
-#define BRP_SPLIT_BARRIER 0  /* measured: no gain (217.7 against 217.0-218.1 ms per 16,384-bit launch on one box): a wavefront waiting at the s_barrier
-                                leaves its SIMD to its partner of the other half, which is behind it anyway.  1 = the "tiles are free again" rendezvous before a level's first transpose store as ARRIVE (after a wavefront's last digit
-                                read of the previous level) + WAIT (before its first store), through a counter in LDS, instead of one s_barrier
-                                behind pass 1: a wavefront no longer waits for the others to REACH the same point of the program, only for them
-                                to have LEFT the multiply-accumulate -- which they did a decomposition step and a pass ago */
+#ifndef BRP_QUARTERS
+#define BRP_QUARTERS 1       /* 1: the last two stages of both passes of a forward transform are issued quarter by quarter (fft_dev.h dft16_quarters), and
+                                the LDS stores of a pass's results -- the transpose's 16, the transformed digits' 16 -- leave from inside those quarters,
+                                spread over half a pass, instead of behind the twiddle multiplies / inside the last stage only: the LDS store path
+                                (13 cycles per ds_write_b128, one path per CU) is what the eight wavefronts of a unit queue for in that stretch */
 #endif
-#ifndef BRP_MASK_IDLE
-#define BRP_MASK_IDLE 0      /* 1: the lane groups that own no polynomial are switched off wherever the program neither writes a tile another
-                                group reads nor requests a key row for their multiply-accumulate role (rotation, decomposition, pass 1, inverse
-                                transform, conversion): EXEC is narrowed by hand around those stretches (as `if (owner)` regions the register
-                                allocator spilled 1,061 registers).  Group 15 of a half is then no mirror of group 14: it gets a scratch tile */
+#ifndef BRP_ZFORM
+#define BRP_ZFORM 0          /* gadget decomposition: 0 = streaming peel (fft_dev.h decompose_next, 5 integer instructions per digit); 2 = z-form (fft_dev.h
+                                zform_first / zform_next: one 64-bit addition resolves every carry, a digit is a byte of the sum minus 127 minus a tie bit),
+                                the tie bits of a lane's 32 coefficients packed in four registers; 1 = z-form WITHOUT the tie bits (every tie rounds up:
+                                digits differ from the reference rule on ties only -- a timing proxy, not a product mode) */
 #endif
 #define BRP_HALF_TILES (EP_GROUPS - 1)                                                   /* 15 tiles per half: group 15 shares group 14's */
 #define BRP_LDS_DOUBLES(R) (2 * FHE_TW_ENTRIES + 2 * BRP_HALF_TILES * GROUP_TILE_DOUBLES + ((R) == 3 ? 6 * FHE_N : 0))   /* R = 3: 159,488 B */
-#define BRP_SYNC_DOUBLES (BRP_SPLIT_BARRIER ? 2 : 0)                                     /* + the arrive counter of the split barrier */
-#define BRP_SCRATCH_DOUBLES (BRP_MASK_IDLE ? GROUP_TILE_DOUBLES : 0)                     /* + the scratch tile of the two switched-off groups 15 */
-static_assert(!(BRP_SPLIT_BARRIER && BRP_MASK_IDLE), "the scratch tile takes the LDS the arrive counter would need");
 #define BRP_PARK_WORDS_PER_HALF (BRP_RESIDENT_HI ? 8 * EP_THREADS * 2 : 16 * EP_THREADS * 2)   /* per half and iteration: 32 KB (lo[] only) or 64 KB */
 
 __device__ __forceinline__ int brp_opaque_tid()
@@ -98,28 +94,13 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
     const bool home_wave = HOME && __builtin_amdgcn_readfirstlane(tq0) >= 16 * HOME_G0;
     double *ldsh = lds + hh * (BRP_HALF_TILES * GROUP_TILE_DOUBLES);                      // this half's tiles (scalar)
     double *ldso = lds + (1 - hh) * (BRP_HALF_TILES * GROUP_TILE_DOUBLES);                // the other half's
-    // MASK: group 15 of either half works in the scratch tile behind the homes (nobody reads it)
-    double *scratch = lds_all + BRP_LDS_DOUBLES(3) + BRP_SYNC_DOUBLES;
-    // wave-uniform: the lanes of this wavefront whose group owns a polynomial; mask_on() narrows EXEC to them, mask_off() restores it.
-    // Done with opaque scalar moves: the compiler sees straight-line code (every value it computes inside such a stretch is consumed
-    // by the owners' work only: lane indices are re-derived per phase from brp_opaque_tid()).
-    const unsigned long long own_mask = __builtin_amdgcn_ballot_w64(g < R * K1);
-    unsigned long long exec_saved = 0;
-    auto mask_on = [&]() {
-        if (BRP_MASK_IDLE) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %1" : "=&s"(exec_saved) : "s"(own_mask) : "memory", "scc"); __builtin_amdgcn_sched_barrier(0); }
-    };
-    auto mask_off = [&]() {
-        if (BRP_MASK_IDLE) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_mov_b64 exec, %0" :: "s"(exec_saved) : "memory"); __builtin_amdgcn_sched_barrier(0); }
-    };
     auto tile_of = [&](const int tq) -> double * {
         int gq = tq >> 4;
-        if (BRP_MASK_IDLE) return gq <= LAST_T ? ldsh + gq * GROUP_TILE_DOUBLES : scratch;
         gq = gq < LAST_T ? gq : LAST_T;
         return ldsh + gq * GROUP_TILE_DOUBLES;
     };
     auto stage_of = [&](const int tq) -> uint64_t * {
         int gq = tq >> 4;
-        if (BRP_MASK_IDLE && gq > LAST_T) return reinterpret_cast<uint64_t *>(scratch);
         gq = gq < LAST_T ? gq : LAST_T;
         if (HOME) {
             const int tile_words = hh * (BRP_HALF_TILES * GROUP_TILE_DOUBLES) + gq * GROUP_TILE_DOUBLES;
@@ -135,50 +116,6 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
     };
 
     ep_load_table(tw, A.tw);
-    // split barrier (BRP_SPLIT_BARRIER): one 32-bit arrive counter behind everything else in LDS; wait number n needs 8 n arrivals
-    unsigned *sync_word = reinterpret_cast<unsigned *>(lds_all + BRP_LDS_DOUBLES(3));
-    if (tid == 0) *sync_word = 0;
-    unsigned sync_target = 0;                                      // scalar
-    typedef __attribute__((address_space(3))) unsigned brp_lds_u32;
-    const unsigned sync_addr = (unsigned)(uintptr_t)(brp_lds_u32 *)sync_word;      // LDS byte address of the counter
-    auto arrive = [&]() {
-        // this wavefront's digit reads have returned; lane 0 adds one (EXEC narrowed inside the sequence: no branch for the compiler)
-        unsigned long long saved;
-        const unsigned one = 1;
-        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
-                     "s_mov_b64 %0, exec\n\t"
-                     "s_mov_b64 exec, 1\n\t"
-                     "ds_add_u32 %1, %2\n\t"
-                     "s_mov_b64 exec, %0\n\t"
-                     "s_waitcnt lgkmcnt(0)"                        /* the compiler's own wait counts know nothing of this LDS operation */
-                     : "=&s"(saved)
-                     : "v"(sync_addr), "v"(one)
-                     : "memory");
-    };
-    auto wait_arrivals = [&]() {
-        sync_target += BRP_THREADS / 64;
-        // The polling loop is ONE opaque instruction sequence (no control flow the register allocator has to reason about: written as
-        // a C loop it cost 60 spilled registers).  Bounded: every wavefront arrives without waiting for anybody (see level_body), so
-        // the count is reached; the bound (2^24 polls) only keeps a wrong build from spinning forever.
-        unsigned vtmp, stmp, scnt;
-        asm volatile("s_mov_b32 %2, 0\n"
-                     "1:\n\t"
-                     "ds_read_b32 %0, %3\n\t"
-                     "s_waitcnt lgkmcnt(0)\n\t"
-                     "v_readfirstlane_b32 %1, %0\n\t"
-                     "s_cmp_ge_u32 %1, %4\n\t"
-                     "s_cbranch_scc1 2f\n\t"
-                     "s_add_u32 %2, %2, 1\n\t"
-                     "s_cmp_lt_u32 %2, 0x1000000\n\t"
-                     "s_cbranch_scc0 2f\n\t"
-                     "s_sleep 1\n\t"
-                     "s_branch 1b\n"
-                     "2:"
-                     : "=&v"(vtmp), "=&s"(stmp), "=&s"(scnt)
-                     : "v"(sync_addr), "s"(sync_target)
-                     : "scc", "memory");
-    };
-
     uint64_t inst = inst0 + (uint64_t)hh * R + r_own;
     const bool valid = inst < A.count;
     if (!valid) inst = A.count - 1;
@@ -234,13 +171,11 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
         }
 #endif
     };
-    mask_on();
     {
         const int tq = brp_opaque_tid() & 255;
 #pragma unroll
         for (int a = 0; a < 16; ++a) stage_park(a, tq);
     }
-    mask_off();
     for (uint32_t it = 0; it < A.iters; ++it) {
         const int t = mod_switch_1024(a_next);
         a_next = lwe[it + 1];
@@ -248,16 +183,21 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 
         // ---- d = acc * X^t - acc; first (least significant) digit ---------------------------------------------------------------
         uint32_t st_lo[16], st_hi[16];
+#if BRP_ZFORM
+        static_assert(BASE_LOG == 8 && LEVELS == 5, "the z-form is written for five levels of eight bits");
+        uint32_t epk[4] = {0, 0, 0, 0};
+#endif
         double xr[16], xi[16];
         double2 w0[8], w1[8];
         EP_STAMP(11);
-        mask_on();
         {
             const int tq = brp_opaque_tid() & 255;
             const int bq_ = tq & 15;
             uint64_t *stage = stage_of(tq);
             wave_lds_sync();
+#if !BRP_QUARTERS
             fft_tw_load8(w0, tw, bq_, FHE_TW_STRIDE);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
@@ -272,13 +212,25 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                 k0[0] = (uint32_t)RND - m0; k0[1] = 0; k1[0] = (uint32_t)RND - m1; k1[1] = 0;
                 const uint64_t x0 = (__builtin_bit_cast(uint64_t, x0w) + lo[a]) + __builtin_bit_cast(uint64_t, k0);
                 const uint64_t x1 = (__builtin_bit_cast(uint64_t, x1w) + hi[a]) + __builtin_bit_cast(uint64_t, k1);
+#if BRP_ZFORM
+                {
+                    uint32_t e_lo, e_hi;
+                    xr[a] = (double)zform_first(x0, st_lo[a], e_lo);
+                    xi[a] = (double)zform_first(x1, st_hi[a], e_hi);
+#if BRP_ZFORM == 2
+                    // coefficient i = 2a (+ 1): tie bits at bit (i % 8) + {0, 8, 16} of epk[i / 8]
+                    if ((2 * a) % 8 == 0) epk[(2 * a) / 8] = e_lo; else epk[(2 * a) / 8] |= e_lo << ((2 * a) % 8);
+                    epk[(2 * a + 1) / 8] |= e_hi << ((2 * a + 1) % 8);
+#endif
+                }
+#else
                 xr[a] = (double)decompose_first_rounded<BASE_LOG, LEVELS>(x0, st_lo[a]);
                 xi[a] = (double)decompose_first_rounded<BASE_LOG, LEVELS>(x1, st_hi[a]);
+#endif
                 if ((a & (EP_ROT_CHUNK - 1)) == EP_ROT_CHUNK - 1) __builtin_amdgcn_sched_barrier(0);
             }
             wave_lds_sync();
         }
-        mask_off();
         EP_STAMP(0);
 
         // sums: local ciphertext r' = 0..RT-1 is ciphertext (r' + R hh) mod RT of the unit, so r' < R are this half's own;
@@ -317,22 +269,88 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
+#if BRP_QUARTERS
+            constexpr int NE = BRP_EARLY, NHOOK = 7, NT = BRP_TAIL;
+            auto early = [&](const int h) { key_rows(NE * h / NHOOK, NE * (h + 1) / NHOOK); };
+            // the table column, just in time: quarter q of pass 1 multiplies by the entries k1 = q, q + 8, q + 4, q + 12 (w0[q], w1[q], w0[q + 4],
+            // w1[q + 4]); the entries of quarters 0 and 1 are requested here (the first two stages hide the LDS round trip), those of
+            // quarter q + 2 behind quarter q, into the registers that quarter has just left: eight entries (32 registers) live at most
+            auto table_quarter = [&](const int q) {
+                w0[q] = tw[q * FHE_TW_STRIDE + bq_]; w1[q] = tw[(q + 8) * FHE_TW_STRIDE + bq_];
+                w0[q + 4] = tw[(q + 4) * FHE_TW_STRIDE + bq_]; w1[q + 4] = tw[(q + 12) * FHE_TW_STRIDE + bq_];
+            };
+            table_quarter(0);
+            table_quarter(1);
+            __builtin_amdgcn_sched_barrier(0);
+            dft16_quarters<false, true, BRP_CHUNK>(xr, xi,
+                [&](const int stage) {
+                    if (stage != 1) return;
+                    __builtin_amdgcn_sched_barrier(0);
+                    EP_STAMP(2);
+#ifndef BRP_ABL_NOBAR
+                    if (tiles_busy) wg_barrier_lds_only();        // every thread of BOTH halves is done reading the previous level's digits
+#endif
+                    EP_STAMP(3);
+#if FFT_XPOSE_PRIO
+                    __builtin_amdgcn_s_setprio(FFT_XPOSE_PRIO);
+#endif
+                },
+                [&](const int q) {
+                    // outputs q, q + 8 (butterfly q) and q + 4, q + 12 (butterfly q + 4) of pass 1 are final: twiddle, transpose store
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k1 = q + 8 * (j & 1) + 4 * (j >> 1), c = fft_reg(k1);
+                        if (k1 < 8) cmul(xr[c], xi[c], w0[k1].x, w0[k1].y); else cmul(xr[c], xi[c], w1[k1 - 8].x, w1[k1 - 8].y);
+                        double2 v; v.x = xr[c]; v.y = xi[c];
+#ifndef BRP_ABL_NOXSTORE
+                        *reinterpret_cast<double2 *>(tile + 2 * (k1 * 17 + bq_)) = v;
+#endif
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (q < 2) { table_quarter(q + 2); __builtin_amdgcn_sched_barrier(0); }
+                    if (NE) early(q);
+                });
+            wave_lds_sync();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int c = fft_reg(q);
+                double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
+                xr[c] = v.x; xi[c] = v.y;
+            }
+            if (NE) { __builtin_amdgcn_sched_barrier(0); early(4); }
+#if FFT_XPOSE_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            dft16_quarters<false, false, BRP_CHUNK>(xr, xi,
+                [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(5 + stage); } },
+                [&](const int q) {
+                    // the transformed digits q, q + 8, q + 4, q + 12 leave for the tile (registers fft_reg(.): dft16_quarters does not rename)
+                    if (q == 0) wave_lds_sync();
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int k2 = q + 8 * (j & 1) + 4 * (j >> 1);
+                        double2 v; v.x = xr[fft_reg(k2)]; v.y = xi[fft_reg(k2)];
+#ifndef BRP_ABL_NODSTORE
+                        *reinterpret_cast<double2 *>(tile + 2 * (bq_ + 16 * k2)) = v;
+#endif
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        constexpr int NL = NQ - NE - NT;
+                        key_rows(NE + NL * q / 4, NE + NL * (q + 1) / 4);
+                    }
+                });
+#else
 #if !BRP_W1_LATE
             fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE);
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            mask_on();
             dft16<false, true, BRP_CHUNK>(xr, xi);
-            mask_off();
             __builtin_amdgcn_sched_barrier(0);
             EP_STAMP(2);
             constexpr int NE = BRP_EARLY, NHOOK = 7, NT = BRP_TAIL;
             auto early = [&](const int h) { key_rows(NE * h / NHOOK, NE * (h + 1) / NHOOK); };
-#if BRP_SPLIT_BARRIER
-            if (tiles_busy) wait_arrivals();                      // every wavefront of BOTH halves has left the previous level's multiply-accumulate
-#else
             if (tiles_busy) wg_barrier_lds_only();                // every thread of BOTH halves is done reading the previous level's digits
-#endif
             EP_STAMP(3);
             {
 #if FFT_XPOSE_PRIO
@@ -390,10 +408,13 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                                         }
                                     });
             }
+#endif
             EP_STAMP(4);
             __builtin_amdgcn_sched_barrier(0);
             EP_STAMP(5);
+#ifndef BRP_ABL_NOBAR
             wg_barrier_lds_only();                                // the digits of all 2R ciphertexts are visible; key loads stay in flight
+#endif
             EP_STAMP(6);
             // ---- multiply-accumulate: thread (hh, tq) owns Fourier point tq; digits of row p for the RT ciphertexts, one row ahead ----
             // local ciphertext r': r' < R in this half's tiles, r' >= R in the other half's (tile (r' mod R) * K1 + p of that half)
@@ -465,27 +486,47 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 #if BRP_MAC_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
-#if BRP_SPLIT_BARRIER
-            if constexpr (!decltype(last)::value) arrive();       // this wavefront no longer reads the digit tiles of this level
-#endif
             EP_STAMP(7);
         };
 
 #pragma unroll 1
         for (int l = LEVELS - 1; l >= 1; --l) {
             level_body(l, l != LEVELS - 1, std::false_type{});
-            mask_on();
             {
                 const int tq = brp_opaque_tid() & 255;
+#if !BRP_QUARTERS
                 fft_tw_load8(w0, tw, tq & 15, FHE_TW_STRIDE);
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
+#if BRP_ZFORM
+            // the next digit is the low byte of the state; the state and the packed tie bits move down one byte per level (the level
+            // loop is rolled: a byte select by level would need a branch, and branches here cost the register allocator its footing)
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                uint32_t e0 = 0, e1 = 0;
+#if BRP_ZFORM == 2
+                e0 = (epk[(2 * a) / 8] >> ((2 * a) % 8)) & 1u;
+                e1 = (epk[(2 * a + 1) / 8] >> ((2 * a + 1) % 8)) & 1u;
+#endif
+                xr[a] = (double)zform_next<0>(st_lo[a], e0);
+                xi[a] = (double)zform_next<0>(st_hi[a], e1);
+                st_lo[a] >>= 8; st_hi[a] >>= 8;
+            }
+#if BRP_ZFORM == 2
+#pragma unroll
+            for (int k = 0; k < 4; ++k) epk[k] >>= 8;
+#endif
+#elif defined(BRP_ABL_NOPEEL)
+#pragma unroll
+            for (int a = 0; a < 16; ++a) { xr[a] = (double)(int)st_lo[a]; xi[a] = (double)(int)st_hi[a]; }
+#else
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
                 xr[a] = (double)decompose_next<BASE_LOG>(st_lo[a]);
                 xi[a] = (double)decompose_next<BASE_LOG>(st_hi[a]);
             }
-            mask_off();
+#endif
             EP_STAMP(1);
         }
         level_body(0, LEVELS > 1, std::true_type{});
@@ -512,7 +553,6 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             }
         }
         wg_barrier_lds_only();
-        mask_on();
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
             double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ + 16 * k2));
@@ -564,7 +604,6 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             stage_park(a, tq);
             if ((a & 1) == 1) __builtin_amdgcn_sched_barrier(0);
         }
-        mask_off();
         EP_STAMP(10);
     }
 #ifdef EP_STAMPS
@@ -602,8 +641,8 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 template <int K1, int LEVELS, int BASE_LOG, int R, int R2>
 __global__ __launch_bounds__(BRP_THREADS, 1) void blind_rotate_pair_kernel(const ExtProdArgs A)
 {
-    __shared__ __attribute__((aligned(16))) double lds_all[BRP_LDS_DOUBLES(R) + BRP_SYNC_DOUBLES + BRP_SCRATCH_DOUBLES];
-    static_assert((BRP_LDS_DOUBLES(R) + BRP_SYNC_DOUBLES + BRP_SCRATCH_DOUBLES) * 8 <= 163840, "one workgroup must fit the 160 KB of a CU");
+    __shared__ __attribute__((aligned(16))) double lds_all[BRP_LDS_DOUBLES(R)];
+    static_assert(BRP_LDS_DOUBLES(R) * 8 <= 163840, "one workgroup must fit the 160 KB of a CU");
     if constexpr (R2 > 0) {
         if (blockIdx.x >= A.units_main) {       // scalar branch
             blind_rotate_pair_unit<K1, LEVELS, BASE_LOG, R2>(A, lds_all, (uint64_t)A.units_main * (2 * R) + (uint64_t)(blockIdx.x - A.units_main) * (2 * R2), blockIdx.x);

@@ -20,6 +20,13 @@ from tfhe_aes_amd.client import Client  # noqa: E402
 
 VARIANTS = {
     "base": [],
+    # ---- round 5: quarter-wise last stages (stores spread over half a pass), z-form decomposition, per-lever proxies ----
+    "q0": ["-DBRP_QUARTERS=0"], "q1_c2": ["-DBRP_CHUNK=2"], "q1_c4": ["-DBRP_CHUNK=4"], "q0_stamps": ["-DBRP_QUARTERS=0", "-DEP_STAMPS"],
+    "z1": ["-DBRP_ZFORM=1"], "z2": ["-DBRP_ZFORM=2"],
+    "noxstore": ["-DBRP_ABL_NOXSTORE"], "nodstore": ["-DBRP_ABL_NODSTORE"], "nostores": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NODSTORE"],
+    "nobar": ["-DBRP_ABL_NOBAR"], "nopeel": ["-DBRP_ABL_NOPEEL"], "noload": ["-DBR16_ABL_NOLOAD"], "nopark": ["-DBR16_ABL_NOPARK"],
+    "nostores_noload": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NODSTORE", "-DBR16_ABL_NOLOAD"],
+    "q1_e7": ["-DBRP_EARLY=7"], "q1_e11": ["-DBRP_EARLY=11"], "q1_t2": ["-DBRP_TAIL=2"], "q1_t6": ["-DBRP_TAIL=6"], "q1_xp0": ["-DFFT_XPOSE_PRIO=0"],
     # ---- round 4: parking ----
     "nohome": ["-DBR16_W3_LDS_HOME=0"],                                   # wavefront 3 parks like the others (idle lanes still skip)
     "r3park": ["-DBR16_W3_LDS_HOME=0", "-DBR16_PARK_OWNERS_ONLY=0"],      # round-3 behaviour: every lane parks
@@ -28,19 +35,17 @@ VARIANTS = {
     "pair_e6": ["-DBRP_EARLY=6"], "pair_e12": ["-DBRP_EARLY=12"], "pair_w1": ["-DBRP_W1_LATE=0"], "pair_norh_w1": ["-DBRP_RESIDENT_HI=0", "-DBRP_W1_LATE=0"],
     "nopair_stamps": ["-DK2_PAIR=0", "-DEP_STAMPS"], "pair_w2": ["-DBRP_W1_LATE=2"], "pair_w2_e6": ["-DBRP_W1_LATE=2", "-DBRP_EARLY=6"], "pair_w2_e12": ["-DBRP_W1_LATE=2", "-DBRP_EARLY=12"],
     "pair_w2_stamps": ["-DBRP_W1_LATE=2", "-DEP_STAMPS"], "pair_w2_nopark": ["-DBRP_W1_LATE=2", "-DBR16_ABL_NOPARK"], "pair_w2_noload": ["-DBRP_W1_LATE=2", "-DBR16_ABL_NOLOAD"],
-    "pair_split": ["-DBRP_SPLIT_BARRIER=1"], "pair_e8": ["-DBRP_EARLY=8"], "pair_e10": ["-DBRP_EARLY=10"], "pair_e7_t3": ["-DBRP_EARLY=7", "-DBRP_TAIL=3"],
+    "pair_e8": ["-DBRP_EARLY=8"], "pair_e10": ["-DBRP_EARLY=10"], "pair_e7_t3": ["-DBRP_EARLY=7", "-DBRP_TAIL=3"],
     "pair_e9_t3": ["-DBRP_TAIL=3"], "pair_e10_t3": ["-DBRP_EARLY=10", "-DBRP_TAIL=3"], "pair_e9_t5": ["-DBRP_TAIL=5"], "pair_e9_t6": ["-DBRP_TAIL=6"], "pair_e8_t5": ["-DBRP_EARLY=8", "-DBRP_TAIL=5"],
     "pair_e10_t5": ["-DBRP_EARLY=10", "-DBRP_TAIL=5"], "pair_e9_t3_pk16": ["-DBRP_TAIL=3", "-DBR16_PARK_AUX_ST=16"], "pair_e9_t3_c2": ["-DBRP_TAIL=3", "-DFFT_CHUNK=2"], "pair_e6_t6": ["-DBRP_EARLY=6", "-DBRP_TAIL=6"],
     "pair_t4_c2": ["-DBRP_TAIL=4", "-DFFT_CHUNK=2"], "pair_t4_c1": ["-DBRP_TAIL=4", "-DFFT_CHUNK=1"], "pair_t4_c8": ["-DBRP_TAIL=4", "-DFFT_CHUNK=8"],
     "pair_e10_t4": ["-DBRP_EARLY=10", "-DBRP_TAIL=4"], "pair_e11_t4": ["-DBRP_EARLY=11", "-DBRP_TAIL=4"], "pair_e8_t4": ["-DBRP_EARLY=8", "-DBRP_TAIL=4"],
-    "pair_t4_pk16": ["-DBRP_TAIL=4", "-DBR16_PARK_AUX_ST=16"], "pair_t4_nobar": ["-DBRP_TAIL=4", "-DFFT_CHUNK_BARRIERS=0"], "pair_t4_split": ["-DBRP_TAIL=4", "-DBRP_SPLIT_BARRIER=1"],
-    "pair_mask": ["-DBRP_MASK_IDLE=1"],
+    "pair_t4_pk16": ["-DBRP_TAIL=4", "-DBR16_PARK_AUX_ST=16"], "pair_t4_nobar": ["-DBRP_TAIL=4", "-DFFT_CHUNK_BARRIERS=0"],
     "pair_mp0": ["-DBRP_MAC_PRIO=0"], "pair_bc4": ["-DBRP_CHUNK=4"], "pair_bc2": ["-DBRP_CHUNK=2"], "pair_mp0_bc4": ["-DBRP_MAC_PRIO=0", "-DBRP_CHUNK=4"], "pair_mp2": ["-DBRP_MAC_PRIO=2"],
     "pair_xprio1": ["-DFFT_XPOSE_PRIO=1"], "pair_xprio3": ["-DFFT_XPOSE_PRIO=3"], "pair_macprio1": ["-DBRP_MAC_PRIO=1"], "pair_macprio3": ["-DBRP_MAC_PRIO=3"],
     "pair_c2": ["-DFFT_CHUNK=2"], "pair_c1": ["-DFFT_CHUNK=1"],
     "pair_e9_t2": ["-DBRP_TAIL=2"], "pair_e9_t4": ["-DBRP_TAIL=4"], "pair_xprio0": ["-DFFT_XPOSE_PRIO=0"], "pair_pk00": ["-DBR16_PARK_AUX_LD=0"], "pair_pk16_2": ["-DBR16_PARK_AUX_ST=16"],
     "pair_chunk2": ["-DFFT_CHUNK=2"], "pair_rot8": ["-DEP_ROT_CHUNK=8"],
-    "pair_nosplit": ["-DBRP_SPLIT_BARRIER=0"], "pair_nosplit_stamps": ["-DBRP_SPLIT_BARRIER=0", "-DEP_STAMPS"],
     "pair_nopark": ["-DBR16_ABL_NOPARK"], "pair_noload": ["-DBR16_ABL_NOLOAD"], "pair_stamps": ["-DEP_STAMPS"],
     "rh": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9"], "rh15": ["-DBR16_RESIDENT_HI=1"], "rh12": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=12"],
     "rh_t0": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9", "-DBR16_MAC_TAIL=0"], "rh_w1": ["-DBR16_RESIDENT_HI=1", "-DBR16_EARLY=9", "-DBR16_W1_LATE=0"],
