@@ -361,8 +361,9 @@ def main():
         l4 = max(1, b4["launches"])
         k2_ms = b4["ms"] / l4
         f4 = (b4["units"] / l4) * p.n * ext_product_flops(p) / (k2_ms * 1e-3) / 1e12 if k2_ms > 0 else 0.0
+        kp4 = eng.k2_plan(int(b4["units"] // l4))
         dec32 = {"blocks_per_s": 32 / dt, "ms": 1000.0 * dt, "verified_vs_aes": bool(ok), "k2_launches": l4, "k2_bits_per_launch": b4["units"] / l4,
-                 "k2_ms_per_launch": k2_ms, "k2_frac_of_f64_valu_peak": f4 / F64_VALU_PEAK_TFLOPS,
+                 "k2_ms_per_launch": k2_ms, "k2_form": kp4["form"], "k2_kernel": kp4["kernel"], "k2_frac_of_f64_valu_peak": f4 / F64_VALU_PEAK_TFLOPS,
                  "note": "BASELINE configs[4] per-GPU shard (256 blocks / 8 GPUs): Server::aes_decrypt on 32 resident blocks, 2,432 bit-CBS per block "
                          "(inverse S-Box + 4-LUT inverse MixColumns packing, server.rs:67-105); one step, every launch is 4,096 bits"}
         del st4
@@ -452,6 +453,8 @@ def main():
             except Exception:
                 pass
         stage_ms = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
+        # the kernel THIS context launches for such a batch (fheaes_k2_context_plan: after the occupancy fallbacks), not an assumption
+        k2p = eng.k2_plan(int(bits_per_launch))
         line = {
             "metric": "AES-128 CTR blocks/sec (FHE)", "value": value, "unit": "blocks/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -474,7 +477,9 @@ def main():
             "two_contexts_64_blocks_each": two_ctx,
             "stage_ms_per_step": stage_ms,
             "roofline": {
-                "kernel": "blind_rotate_pair_kernel (blind rotation, K2)", "bound": "valu_f64",
+                "kernel": "%s (blind rotation, K2)" % k2p["kernel"], "k2_form": k2p["form"],
+                "k2_plan": {"units_main": k2p["units_main"], "r_main": k2p["r_main"], "units_tail": k2p["units_tail"], "r_tail": k2p["r_tail"]},
+                "bound": "valu_f64",
                 "achieved": tflops, "peak": F64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / F64_VALU_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": avg_ms, "bits_per_launch": bits_per_launch,
                 "traffic_over_algorithmic": None if traffic is None else traffic / algo_bytes,

@@ -109,11 +109,13 @@ int fheaes_clone_info(fheaes_ctx *ctx, int *path, uint64_t *bytes, double *secon
 
 /* ---- noise guard ---------------------------------------------------------------- */
 /* The reference builds tfhe-rs with `noise-asserts` (Cargo.toml:7) under MaxNoiseLevel::new(5) (client.rs:92): a sum of more than
- * five nominal-noise ciphertexts between two bootstraps panics (many_wopbs.rs:101-108 resets every WoPBS output to NOMINAL).  The
- * engine's linear layers (MixColumns + AddRoundKey = 4 + 1, the key-expansion sums = 2) count the same way: a schedule that would
- * exceed the limit is refused with FHEAES_ERR_INVALID instead of producing undecryptable words, and the highest level any call on
- * this context has produced can be read back.  Callers that add ciphertext words themselves (the stage-level entry points hand out
- * raw uint64 words, which carry no metadata) keep their own count, as users of tfhe-rs' `unchecked_*` do. */
+ * five nominal-noise ciphertexts between two bootstraps panics (many_wopbs.rs:101-108 resets every WoPBS output to NOMINAL).
+ * What the engine has is a STATIC SCHEDULE ASSERTION, not runtime noise tracking: each linear layer of the engine's own AES schedule
+ * declares how many WoPBS outputs it sums per output word (MixColumns + AddRoundKey = 4 + 1, the key-expansion sums = 2); a layer
+ * whose gather table would sum more than the limit is refused with FHEAES_ERR_INVALID, and the largest count any call on this context
+ * has declared can be read back.  Ciphertext words carry no noise metadata: a state that a caller has already summed before passing
+ * it in counts as nominal here.  Callers that add ciphertext words themselves (the stage-level entry points hand out raw uint64
+ * words) keep their own count, as users of tfhe-rs' `unchecked_*` do. */
 #define FHEAES_MAX_NOISE_LEVEL 5
 int fheaes_noise_level_seen(fheaes_ctx *ctx, uint32_t *max_seen, uint32_t *limit);
 
@@ -191,11 +193,20 @@ int fheaes_get_twiddles(double *psi_out);
 /* Fourier image of GGSW `i` of the uploaded BSK: out [pbs_level][k+1][k+1][256][2] */
 int fheaes_read_bsk_fourier(fheaes_ctx *ctx, uint32_t i, double *out);
 /* How a blind-rotation launch of `m` bits is cut into workgroups on a device with `cu_count` compute units at GLWE dimension k
- * (host logic only, no GPU needed): `form` 0 = latency form (one ciphertext per workgroup), 1 = throughput form; `units_main`
- * workgroups of `r_main` ciphertexts followed by `units_tail` of `r_tail`.  With more workgroups than the device has slots (two per
- * CU) the counts make the launch a whole number of generations that covers the batch exactly. */
+ * (host logic only, no GPU needed, DEVICE-INDEPENDENT: the plan a device takes when every kernel form can be placed on it).
+ * `form` 0 = latency form (kern_blindrot_latency.h: one ciphertext per 512-thread workgroup, m <= 256), 1 = 16-form
+ * (kern_blindrot16.h: 256-thread workgroups of 3 / 2 ciphertexts, two per CU; 257..768 bits, and every batch at k = 1),
+ * 2 = paired form (kern_blindrot_pair.h: ONE 512-thread workgroup per CU carrying 6 / 4 ciphertexts; k = 4, m > 768).
+ * `units_main` workgroups of `r_main` ciphertexts are followed by `units_tail` of `r_tail`.  With more workgroups than the device has
+ * slots (form 1: two per CU, form 2: one per CU) the counts make the launch a whole number of generations that covers the batch exactly. */
 int fheaes_k2_launch_plan(uint64_t m, uint32_t cu_count, uint32_t k, int *form, uint64_t *units_main, uint32_t *r_main,
                           uint64_t *units_tail, uint32_t *r_tail);
+/* The same for a CONTEXT: the form and the kernel this context really launches for a batch of `m` bits on its device, after the
+ * occupancy fallbacks (the paired kernel needs 159,488 B of LDS per workgroup: where the runtime cannot place one on a CU every batch
+ * takes form 1; the 16-form's LDS-home variant needs two workgroups of 81,920 B per CU, else its parked variant runs).  `kernel`
+ * (may be NULL) receives the kernel's name, e.g. "blind_rotate_pair_kernel<5,5,8,3,2>".  Measurements must be labelled from this call. */
+int fheaes_k2_context_plan(fheaes_ctx *ctx, uint64_t m, int *form, uint64_t *units_main, uint32_t *r_main, uint64_t *units_tail,
+                           uint32_t *r_tail, char *kernel, size_t kernel_cap);
 const char *fheaes_version(void);
 
 #ifdef __cplusplus

@@ -101,16 +101,26 @@ def test_aes_pipeline_bit_exact_and_golden(golden):
     c.test_verify(enc, srv.aes_decryption(rk, enc.copy()))  # Client::test_verify (client.rs:178-216)
 
 
+@pytest.fixture(scope="module")
+def opt_server(opt):
+    return Server(opt.keys, device=0, engine=opt.engine())
+
+
+@pytest.mark.parametrize("which", ["toy", "opt"])
 @pytest.mark.parametrize("idx", range(5))
-def test_known_answer_vectors_on_gpu(toy, toy_server, golden, idx):
+def test_known_answer_vectors_on_gpu(request, golden, which, idx):
+    """The reference's own known answers (src/main.rs:78-95: the four SP 800-38A F.1.1 pairs) + FIPS-197 C.1, on the HIP path at the
+    toy set AND at the reference's parameter set (PARAM_OPT, k = 4: the latency / paired kernels): key expansion -> encrypt ->
+    decrypt, checked both ways as Client::test_verify does (client.rs:178-216)."""
+    kit, srv = request.getfixturevalue(which), request.getfixturevalue(which + "_server")
     v = golden["aes_kat"][idx]
     key, pt, want = int(v["key"], 16), int(v["plaintext"], 16), int(v["ciphertext"], 16)
-    c = toy.client
-    rk = toy_server.aes_key_expansion(c.encrypt_u128(key))
+    c = kit.client
+    rk = srv.aes_key_expansion(c.encrypt_u128(key))
     assert np.array_equal(c.decrypt_bytes(rk), np.array(aes_clear.expand_key(key), dtype=np.uint8))
-    enc = toy_server.aes_encrypt(rk, c.encrypt_u128(pt))
+    enc = srv.aes_encrypt(rk, c.encrypt_u128(pt))
     assert c.decrypt_u128(enc) == want
-    assert c.decrypt_u128(toy_server.aes_decrypt(rk, enc.copy())) == pt
+    assert c.decrypt_u128(srv.aes_decrypt(rk, enc.copy())) == pt
 
 
 def test_batched_blocks_equal_per_block_oracle(toy, toy_server):
@@ -250,8 +260,9 @@ def test_full_block_bit_exact_param_opt(opt):
 
 
 def test_noise_guard_counts_what_the_schedule_sums(toy, toy_server):
-    """the engine's counterpart of tfhe-rs' noise-asserts (Cargo.toml:7, MaxNoiseLevel::new(5) at client.rs:92): the linear layers
-    count the nominal-noise ciphertexts they sum between two bootstraps -- MixColumns (4 terms) + AddRoundKey = 5, the limit"""
+    """the engine's counterpart of tfhe-rs' noise-asserts (Cargo.toml:7, MaxNoiseLevel::new(5) at client.rs:92), as a static assertion on
+    the engine's own schedule (not runtime noise tracking): the linear layers declare how many WoPBS outputs they sum per word --
+    MixColumns (4 terms) + AddRoundKey = 5, the limit"""
     c = toy.client
     rk = toy_server.aes_key_expansion(c.encrypt_u128(c.key))
     seen, limit = toy_server.engine.noise_level_seen()

@@ -23,12 +23,12 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _run_bench(nproc: int, extra):
+def _run_bench(nproc, extra, params="toy"):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["MASTER_ADDR"] = "127.0.0.1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", str(nproc), "--backend", "gloo", "--params", "toy"] + extra
+           "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", str(nproc), "--backend", "gloo", "--params", params] + extra
     res = subprocess.run(cmd, cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -44,6 +44,8 @@ def test_bench_two_ranks_gloo():
     assert line["unit"] == "blocks/s" and line["value"] > 0
     assert "cpu_baseline" in line and line["cpu_baseline"]["kind"] == "port"        # present for every world size
     assert line["roofline"]["bound"] == "valu_f64" and "hbm" in line["roofline"]
+    # the kernel named is the one the context reports (fheaes_k2_context_plan), with its form
+    assert "k2_form" in line["roofline"] and line["roofline"]["kernel"].startswith(("blind_rotate_pair_kernel", "blind_rotate16_kernel", "blind_rotate_latency_kernel"))
     # present (null unless a counter file of these very sources exists); round 3's `valu_busy` is gone: it was not a busy fraction
     for k in ("ceiling_frac", "valu_issue_occupancy_model", "sq_insts_valu", "clock_ghz", "model_frac", "traffic", "traffic_over_algorithmic",
               "l1_fill_bytes_per_clk_per_cu", "power"):
@@ -58,6 +60,23 @@ def test_bench_two_ranks_gloo():
     assert col["key_broadcast_bytes"] > 0 and col["key_broadcast_GBps"] > 0
     assert len(col["rank_elapsed_s"]["per_rank"]) == 2 and col["rank_elapsed_s"]["min"] <= col["rank_elapsed_s"]["max"]
     assert abs(col["rank_elapsed_s"]["max"] * 1000.0 / line["steps"] - line["ms_per_step"]) < 1e-6 * line["ms_per_step"] + 1e-3
+
+
+def test_bench_two_ranks_gloo_at_param_opt():
+    """The N > 1 path at the REAL parameter set (main.rs:55-64 is what it stands for), rehearsed on the one GPU there is: two fresh child
+    ranks share the card; rank 0 generates the PARAM_OPT keys, the seeded form (194,494,496 B) crosses the process group, every rank
+    regenerates the masks on the GPU (fheaes_upload_keys_seeded), takes its shard of the blocks, and rank 0 verifies against AES.  The
+    first real 8-GPU run must not be the first time real-size keys cross this path."""
+    line = _run_bench(2, ["--blocks", "8", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], params="opt")
+    assert line["n_gpus"] == 2 and line["config"]["params"] == "PARAM_OPT"
+    assert line["verified_vs_aes"] is True
+    assert line["config"]["total_blocks"] == 16
+    col = line["collective"]
+    assert col["world_size_seen"] == 2 and col["backend"] == "gloo" and col["data_path_collectives"] == 0
+    assert col["key_broadcast_bytes"] == 194_494_496
+    assert len(col["rank_elapsed_s"]["per_rank"]) == 2 and min(col["rank_elapsed_s"]["per_rank"]) > 0
+    # 8 blocks per rank = 1,024-bit launches: the paired kernel (form 2) on the MI355X
+    assert line["roofline"]["k2_form"] == 2 and line["roofline"]["bits_per_launch"] == 1024
 
 
 def test_bench_one_rank_through_rccl():

@@ -139,9 +139,15 @@ def test_k2_launch_forms_agree_at_full_size(opt):
         rm, rt = C.c_uint32(), C.c_uint32()
         assert lib.fheaes_k2_launch_plan(m, 256, 4, C.byref(f), C.byref(um), C.byref(rm), C.byref(ut), C.byref(rt)) == 0
         return f.value
-    assert (form(16384), form(4096), form(1024), form(768), form(256)) == (2, 2, 2, 1, 0)     # which kernel each cut below runs
+    assert (form(16384), form(4096), form(1024), form(768), form(256)) == (2, 2, 2, 1, 0)     # the device-independent plan of each cut below
 
     p, E = opt.params, opt.engine()
+    # ... and what THIS context really launches on the MI355X (fheaes_k2_context_plan: after the occupancy queries): the paired kernel
+    # must be placeable here, or every number published under its name would be another kernel's
+    got = [E.k2_plan(m_) for m_ in (16384, 4096, 1024, 768, 256)]
+    assert [g["form"] for g in got] == [2, 2, 2, 1, 0]
+    assert got[0]["kernel"].startswith("blind_rotate_pair_kernel") and (got[0]["units_main"], got[0]["r_main"], got[0]["units_tail"], got[0]["r_tail"]) == (2560, 6, 256, 4)
+    assert got[3]["kernel"].startswith("blind_rotate16_kernel<5,5,8,3,2,true") and got[4]["kernel"].startswith("blind_rotate_latency_kernel<5")
     rng = np.random.default_rng(16384)
     m = 16384
     small = torch.from_numpy(rng.integers(0, 1 << 64, (m, p.n + 1), dtype=np.uint64).view(np.int64)).cuda()

@@ -60,6 +60,8 @@ SIGNATURES = {
     "fheaes_read_bsk_fourier": (_c.c_int, [_ctx, _c.c_uint32, _dp]),
     "fheaes_k2_launch_plan": (_c.c_int, [_c.c_uint64, _c.c_uint32, _c.c_uint32, _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint32),
                                        _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint32)]),
+    "fheaes_k2_context_plan": (_c.c_int, [_ctx, _c.c_uint64, _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint32),
+                                        _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint32), _c.c_char_p, _c.c_size_t]),
     "fheaes_version": (_c.c_char_p, []),
 }
 
@@ -260,6 +262,14 @@ class Engine:
             self._check(self._lib.fheaes_profile_read(self._h, i, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(units)))
             out[name] = {"ms": ms.value, "launches": launches.value, "units": units.value}
         return out
+
+    def k2_plan(self, bits: int) -> dict:
+        """the blind-rotation kernel this context really launches for a batch of `bits` (after the occupancy fallbacks) and its cut"""
+        form, um, rm, ut, rt = _c.c_int(), _c.c_uint64(), _c.c_uint32(), _c.c_uint64(), _c.c_uint32()
+        name = _c.create_string_buffer(96)
+        self._check(self.lib.fheaes_k2_context_plan(self.h, bits, _c.byref(form), _c.byref(um), _c.byref(rm), _c.byref(ut), _c.byref(rt), name, len(name)))
+        return {"form": form.value, "kernel": name.value.decode(), "units_main": um.value, "r_main": rm.value,
+                "units_tail": ut.value, "r_tail": rt.value}
 
     def read_bsk_fourier(self, i: int) -> np.ndarray:
         p = self.params

@@ -380,6 +380,10 @@ struct StampReport {
 #ifndef K2_PAIR_MIN_BITS
 #define K2_PAIR_MIN_BITS 768ull
 #endif
+#ifndef K2_PAIR_TAIL4
+#define K2_PAIR_TAIL4 1                /* 1: the paired form fills its last generation with four-ciphertext units on every CU; 0: six-ciphertext units only
+                                          (the last generation then covers fewer CUs) -- measured at 4,096 bits, see DESIGN.md */
+#endif
 struct K2Plan { int form; uint64_t units_main; uint32_t r_main; uint64_t units_tail; uint32_t r_tail; };
 K2Plan k2_plan(uint64_t m, uint32_t cu_count, uint32_t k1, bool allow_pair = true)
 {
@@ -393,6 +397,7 @@ K2Plan k2_plan(uint64_t m, uint32_t cu_count, uint32_t k1, bool allow_pair = tru
         const uint64_t gens = (m + 6ull * cu_count - 1) / (6ull * cu_count);
         uint64_t nu = gens * cu_count;
         uint64_t four = 6 * nu >= m ? (6 * nu - m) / 2 : 0;      // units that can give up two of their six slots
+        if (!K2_PAIR_TAIL4) { pl.units_main = (m + 5) / 6; pl.units_tail = 0; return pl; }
         if (four > nu) four = nu;
         if (four == nu && 4 * nu > m) { nu = (m + 3) / 4; four = nu; }          // less than one generation of 4-ciphertext units
         pl.units_tail = four; pl.units_main = nu - four;
@@ -494,6 +499,32 @@ bool k2_pair_allowed(fheaes_ctx *c)
     return c->k2_pair_ok == 1;
 }
 
+// the 16-form's LDS-home variant takes exactly half of a CU's 160 KB per workgroup: use it only where the runtime really places two
+bool k2_home_allowed(fheaes_ctx *c)
+{
+    if (c->k1 != 5) return false;
+    if (c->k2_home < 0) {
+        int per_cu = 0;
+        const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blind_rotate16_kernel<5, 5, 8, 3, 2, true>, EP_THREADS, 0);
+        c->k2_home = (BR16_W3_LDS_HOME && oe == hipSuccess && per_cu >= 2) ? 1 : 0;
+        (void)hipGetLastError();         // a failed query means "fall back", not a failed launch
+    }
+    return c->k2_home == 1;
+}
+
+// the kernel a blind-rotation batch of m bits really takes on this context (form of K2Plan after the occupancy fallbacks) and its name
+K2Plan k2_context_plan(fheaes_ctx *c, uint64_t m, const char **kernel)
+{
+    const K2Plan pl = k2_plan(m, c->cu_count, c->k1, k2_pair_allowed(c));
+    if (kernel) {
+        if (pl.form == 0) *kernel = c->k1 == 5 ? "blind_rotate_latency_kernel<5,5,8>" : "blind_rotate_latency_kernel<2,5,8>";
+        else if (pl.form == 2) *kernel = "blind_rotate_pair_kernel<5,5,8,3,2>";
+        else if (c->k1 != 5) *kernel = "blind_rotate16_kernel<2,5,8,8,0,false>";
+        else *kernel = k2_home_allowed(c) ? "blind_rotate16_kernel<5,5,8,3,2,true>" : "blind_rotate16_kernel<5,5,8,3,2,false>";
+    }
+    return pl;
+}
+
 int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_t level, uint64_t *out)
 {
     if (m == 0) return FHEAES_OK;
@@ -520,7 +551,7 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         //  one-ciphertext-per-workgroup form of kern_extprod.h took 21.6 ms there and the latency form in two waves 16-18 ms)
     } else if (k2_plan(m, c->cu_count, c->k1, k2_pair_allowed(c)).form == 2) {
         // paired throughput form (kern_blindrot_pair.h): one 512-thread workgroup per CU, 6 (or 4) ciphertexts share every key fetch
-        const K2Plan pl = k2_plan(m, c->cu_count, c->k1);
+        const K2Plan pl = k2_plan(m, c->cu_count, c->k1, true);
         const unsigned gridp = (unsigned)(pl.units_main + pl.units_tail);
         a.units_main = (uint32_t)pl.units_main;
         const size_t park_bytes = (size_t)gridp * 2 * BRP_PARK_WORDS_PER_HALF * 8;
@@ -549,13 +580,7 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         StampReport rep(c, (size_t)grid16 * 4, names16);
         a.stamps = rep.d;
 #endif
-        if (c->k2_home < 0) {
-            // the LDS-home form takes exactly half of a CU's 160 KB per workgroup: use it only where the runtime really places two
-            int per_cu = 0;
-            const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blind_rotate16_kernel<5, 5, 8, 3, 2, true>, EP_THREADS, 0);
-            c->k2_home = (BR16_W3_LDS_HOME && oe == hipSuccess && per_cu >= 2) ? 1 : 0;
-        }
-        if (c->k1 == 5 && c->k2_home == 1) hipLaunchKernelGGL((blind_rotate16_kernel<5, 5, 8, 3, 2, true>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
+        if (c->k1 == 5 && k2_home_allowed(c)) hipLaunchKernelGGL((blind_rotate16_kernel<5, 5, 8, 3, 2, true>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
         else if (c->k1 == 5) hipLaunchKernelGGL((blind_rotate16_kernel<5, 5, 8, 3, 2, false>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
         else hipLaunchKernelGGL((blind_rotate16_kernel<2, 5, 8, 8>), dim3(grid16), dim3(EP_THREADS), 0, c->stream, a);
     }
@@ -617,7 +642,8 @@ int launch_vertical_packing(fheaes_ctx *c, const double2 *ggswf, uint64_t n_inpu
     return FHEAES_OK;
 }
 
-// every sum of ciphertexts between two bootstraps goes through here: refuse what tfhe-rs' noise-asserts would panic on
+// static schedule assertion (NOT runtime noise tracking: words carry no metadata): every linear layer of the engine's own AES schedule
+// declares here how many WoPBS outputs it sums per word; a table that would sum more than tfhe-rs' noise-asserts allow is refused
 int noise_guard(fheaes_ctx *c, uint32_t level, const char *what)
 {
     if (level > c->noise_level_seen) c->noise_level_seen = level;
@@ -758,6 +784,18 @@ int fheaes_k2_launch_plan(uint64_t m, uint32_t cu_count, uint32_t k, int *form, 
     if (!form || !units_main || !r_main || !units_tail || !r_tail || cu_count == 0 || m == 0) return FHEAES_ERR_INVALID;
     const K2Plan pl = k2_plan(m, cu_count, k + 1);
     *form = pl.form; *units_main = pl.units_main; *r_main = pl.r_main; *units_tail = pl.units_tail; *r_tail = pl.r_tail;
+    return FHEAES_OK;
+}
+int fheaes_k2_context_plan(fheaes_ctx *ctx, uint64_t m, int *form, uint64_t *units_main, uint32_t *r_main, uint64_t *units_tail,
+                           uint32_t *r_tail, char *kernel, size_t kernel_cap)
+{
+    if (!ctx) return FHEAES_ERR_INVALID;
+    CtxLock lock__(ctx);
+    if (!form || !units_main || !r_main || !units_tail || !r_tail || m == 0) return ctx->fail(FHEAES_ERR_INVALID, "k2_context_plan: null output or empty batch");
+    const char *name = "";
+    const K2Plan pl = k2_context_plan(ctx, m, &name);
+    *form = pl.form; *units_main = pl.units_main; *r_main = pl.r_main; *units_tail = pl.units_tail; *r_tail = pl.r_tail;
+    if (kernel && kernel_cap) { std::strncpy(kernel, name, kernel_cap - 1); kernel[kernel_cap - 1] = 0; }
     return FHEAES_OK;
 }
 const char *fheaes_version(void) { return FHEAES_VERSION_STR; }

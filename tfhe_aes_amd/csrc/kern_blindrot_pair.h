@@ -176,6 +176,10 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 #pragma unroll
         for (int a = 0; a < 16; ++a) stage_park(a, tq);
     }
+#ifdef BRP_ABL_SKEW
+    // timing proxy (with BRP_ABL_NOBAR: no barrier is left in the loop): half 1 starts BRP_ABL_SKEW x 64 cycles late and the halves free-run
+    if (hh) for (int i = 0; i < BRP_ABL_SKEW; i += 100) __builtin_amdgcn_s_sleep(100);
+#endif
     for (uint32_t it = 0; it < A.iters; ++it) {
         const int t = mod_switch_1024(a_next);
         a_next = lwe[it + 1];
@@ -304,6 +308,8 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                         double2 v; v.x = xr[c]; v.y = xi[c];
 #ifndef BRP_ABL_NOXSTORE
                         *reinterpret_cast<double2 *>(tile + 2 * (k1 * 17 + bq_)) = v;
+#else
+                        asm volatile("" :: "v"(v.x), "v"(v.y));   // timing proxy: the values are computed, the store is not issued
 #endif
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -311,12 +317,14 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                     if (NE) early(q);
                 });
             wave_lds_sync();
+#ifndef BRP_ABL_NOXREAD
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int c = fft_reg(q);
                 double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
                 xr[c] = v.x; xi[c] = v.y;
             }
+#endif
             if (NE) { __builtin_amdgcn_sched_barrier(0); early(4); }
 #if FFT_XPOSE_PRIO
             __builtin_amdgcn_s_setprio(0);
@@ -332,6 +340,8 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                         double2 v; v.x = xr[fft_reg(k2)]; v.y = xi[fft_reg(k2)];
 #ifndef BRP_ABL_NODSTORE
                         *reinterpret_cast<double2 *>(tile + 2 * (bq_ + 16 * k2)) = v;
+#else
+                        asm volatile("" :: "v"(v.x), "v"(v.y));
 #endif
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -350,7 +360,9 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             EP_STAMP(2);
             constexpr int NE = BRP_EARLY, NHOOK = 7, NT = BRP_TAIL;
             auto early = [&](const int h) { key_rows(NE * h / NHOOK, NE * (h + 1) / NHOOK); };
+#ifndef BRP_ABL_NOBAR
             if (tiles_busy) wg_barrier_lds_only();                // every thread of BOTH halves is done reading the previous level's digits
+#endif
             EP_STAMP(3);
             {
 #if FFT_XPOSE_PRIO
@@ -535,7 +547,9 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
         const int bq_ = tq & 15;
         double *tile = tile_of(tq);
         // ---- products back to the owning groups: column c of local ciphertext r' goes to tile (r' mod R) * K1 + c of its half ------
+#if !(defined(BRP_ABL_NOBAR) && defined(BRP_ABL_SKEW))
         wg_barrier_lds_only();
+#endif
         {
             double *own = ldsh + 2 * tq, *oth = ldso + 2 * tq;
             const int c0 = 2 * hh;                                 // scalar
@@ -552,7 +566,9 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                 *reinterpret_cast<double2 *>(own + (r * K1 + K1 - 1) * GROUP_TILE_DOUBLES) = v;
             }
         }
+#if !(defined(BRP_ABL_NOBAR) && defined(BRP_ABL_SKEW))
         wg_barrier_lds_only();
+#endif
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
             double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ + 16 * k2));

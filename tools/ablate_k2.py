@@ -24,8 +24,12 @@ VARIANTS = {
     "q0": ["-DBRP_QUARTERS=0"], "q1_c2": ["-DBRP_CHUNK=2"], "q1_c4": ["-DBRP_CHUNK=4"], "q0_stamps": ["-DBRP_QUARTERS=0", "-DEP_STAMPS"],
     "z1": ["-DBRP_ZFORM=1"], "z2": ["-DBRP_ZFORM=2"],
     "noxstore": ["-DBRP_ABL_NOXSTORE"], "nodstore": ["-DBRP_ABL_NODSTORE"], "nostores": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NODSTORE"],
-    "nobar": ["-DBRP_ABL_NOBAR"], "nopeel": ["-DBRP_ABL_NOPEEL"], "noload": ["-DBR16_ABL_NOLOAD"], "nopark": ["-DBR16_ABL_NOPARK"],
+    "noxread": ["-DBRP_ABL_NOXREAD"], "noxpose": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NOXREAD"], "nolds_fwd": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NOXREAD", "-DBRP_ABL_NODSTORE"],
+    "nobar": ["-DBRP_ABL_NOBAR"], "nobar_skew0": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=0"], "nobar_skew40": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=40"],
+    "nobar_skew80": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=80"], "nobar_skew160": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=160"],
+    "q0_nobar_skew0": ["-DBRP_QUARTERS=0", "-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=0"], "q0_nobar_skew80": ["-DBRP_QUARTERS=0", "-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=80"], "nopeel": ["-DBRP_ABL_NOPEEL"], "noload": ["-DBR16_ABL_NOLOAD"], "nopark": ["-DBR16_ABL_NOPARK"],
     "nostores_noload": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NODSTORE", "-DBR16_ABL_NOLOAD"],
+    "all6": ["-DK2_PAIR_TAIL4=0"],
     "q1_e7": ["-DBRP_EARLY=7"], "q1_e11": ["-DBRP_EARLY=11"], "q1_t2": ["-DBRP_TAIL=2"], "q1_t6": ["-DBRP_TAIL=6"], "q1_xp0": ["-DFFT_XPOSE_PRIO=0"],
     # ---- round 4: parking ----
     "nohome": ["-DBR16_W3_LDS_HOME=0"],                                   # wavefront 3 parks like the others (idle lanes still skip)
