@@ -44,6 +44,9 @@
  *     levels from the LEAST significant (l = L-1) to the most significant (l = 0), rows r
  *     ascending inside a level:  re = fma(dr,br,re); re = fma(-di,bi,re);
  *                             im = fma(dr,bi,im); im = fma( di,br,im);
+ *   - gadget decomposition: the key switches (K1, K3) use tfhe-rs' SignedDecomposer rule (decompose); the external products
+ *     (blind rotation, CMUX) use the same closest-representable rounding followed by the OFFSET rule of the original TFHE
+ *     library (decompose_offset; canonical form v3, round 5): same recomposed value, digits in [-B/2, B/2), ties always carry;
  *   - back-conversion: w = v*2^-72; w -= rint(w); r = rint(w*2^64) -> int64, wrapping add;
  *   - twiddles: psi^j = exp(i*pi*j/512) from long-double half-angle recurrences (see
  *     init_twiddles), so they do not depend on libm;
@@ -341,6 +344,24 @@ static inline void decompose(uint64_t x, int b, int level, int32_t *dig)
 
 void orc_decompose(uint64_t x, int base_log, int level, int32_t *out) { decompose(x, base_log, level, out); }
 
+/* Decomposition of the EXTERNAL PRODUCTS (blind rotation, CMUX) -- canonical form v3 (round 5): the same
+ * closest-representable rounding as above, then the OFFSET rule of the original TFHE library (tGswTorus32PolynomialDecompH):
+ *     z = (x + 2^(r-1)) + sum_l (B/2) 2^(64 - b (l+1)),    dig[l] = (bits [64 - b (l+1), 64 - b l) of z) - B/2   in [-B/2, B/2).
+ * It recomposes to the same value mod 2^64 as decompose() and gives the same digits except where a digit is exactly +-B/2 (a tie
+ * always carries here; the tfhe-rs rule lets the next digit's top bit decide).  The key switches (K1, K3) keep decompose(): their
+ * integer results could be compared with tfhe-rs word for word; behind the f64 FFT of an external product no such comparison
+ * exists (ciphertext-level parity unpinned), and on the GPU this rule is one instruction per digit instead of five. */
+static inline void decompose_offset(uint64_t x, int b, int level, int32_t *dig)
+{
+    int r = 64 - b * level;
+    uint64_t z = x + (r > 0 ? 1ULL << (r - 1) : 0);
+    for (int l = 0; l < level; ++l) z += (1ULL << (b - 1)) << (64 - b * (l + 1));
+    uint64_t mask = (1ULL << b) - 1;
+    for (int l = 0; l < level; ++l) dig[l] = (int32_t)((z >> (64 - b * (l + 1))) & mask) - (int32_t)(1 << (b - 1));
+}
+
+void orc_decompose_offset(uint64_t x, int base_log, int level, int32_t *out) { decompose_offset(x, base_log, level, out); }
+
 static inline int mod_switch(uint64_t x) { return (int)(((x + (1ULL << 53)) >> 54) & 1023); }
 int orc_mod_switch(uint64_t x) { return mod_switch(x); }
 
@@ -369,7 +390,7 @@ static void ext_product_add(int k1, int level, int base_log, const double *gf,
     int32_t dg[8];
     for (int r = 0; r < k1; ++r) {
         for (int j = 0; j < NPOLY; ++j) {
-            decompose(d[r * NPOLY + j], base_log, level, dg);
+            decompose_offset(d[r * NPOLY + j], base_log, level, dg);
             for (int l = 0; l < level; ++l) dig[l][j] = (double)dg[l];
         }
         for (int l = 0; l < level; ++l) {

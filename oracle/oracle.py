@@ -53,6 +53,7 @@ def lib():
             "orc_negacyclic_mul_fft": (None, [i64p, u64p, u64p]),
             "orc_negacyclic_mul_exact": (None, [i64p, u64p, u64p]),
             "orc_decompose": (None, [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, i32p]),
+            "orc_decompose_offset": (None, [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, i32p]),
             "orc_mod_switch": (ctypes.c_int, [ctypes.c_uint64]),
             "orc_polys_to_fourier": (None, [u64p, ctypes.c_int64, dp]),
             "orc_external_product_add": (None, [pp, ctypes.c_int, ctypes.c_int, u64p, u64p, u64p]),
@@ -105,6 +106,13 @@ def twiddles() -> np.ndarray:
 def decompose(x: int, base_log: int, level: int) -> np.ndarray:
     out = np.empty(level, dtype=np.int32)
     lib().orc_decompose(ctypes.c_uint64(x), base_log, level, _p(out, ctypes.c_int32))
+    return out
+
+
+def decompose_offset(x: int, base_log: int, level: int) -> np.ndarray:
+    """the decomposition of the external products (canonical form v3): closest-representable rounding, then the offset rule"""
+    out = np.empty(level, dtype=np.int32)
+    lib().orc_decompose_offset(ctypes.c_uint64(x), base_log, level, _p(out, ctypes.c_int32))
     return out
 
 

@@ -82,7 +82,7 @@ def opt_section(kit=None):
     got = orc.external_product_add(p, level, b, ggsw, d, acc0)
     want = acc0.copy()
     for r in range(k1):
-        digs = np.array([orc.decompose(int(v), b, level) for v in d[r]], dtype=np.int64)
+        digs = np.array([orc.decompose_offset(int(v), b, level) for v in d[r]], dtype=np.int64)
         for l in range(level):
             for cc in range(k1):
                 want[cc] += orc.negacyclic_mul_exact(digs[:, l], ggsw[l, r, cc])

@@ -39,6 +39,43 @@ def test_decomposition(b, level):
         assert recomposed == closest
 
 
+def _decompose_offset_restated(x, b, level):
+    """canonical form v3 (external products): closest representable, then the offset rule of the original TFHE library:
+    digit_l = ((x' + sum_l (B/2) 2^(64 - b(l+1))) >> (64 - b(l+1))) mod B - B/2"""
+    r = 64 - b * level
+    z = (x + ((1 << (r - 1)) if r > 0 else 0)) & M64
+    for l in range(level):
+        z = (z + ((1 << (b - 1)) << (64 - b * (l + 1)))) & M64
+    return [((z >> (64 - b * (l + 1))) & ((1 << b) - 1)) - (1 << (b - 1)) for l in range(level)]
+
+
+@pytest.mark.parametrize("b,level", [(8, 5), (15, 1), (8, 2), (4, 8)])
+def test_offset_decomposition_of_the_external_products(b, level):
+    """the rule the external products use since round 5: same recomposed value as the tfhe-rs rule (the closest representable),
+    digits in [-B/2, B/2), identical digits wherever the tfhe-rs rule produces no digit of magnitude B/2"""
+    rng = np.random.default_rng(b * 1000 + level)
+    r = 64 - b * level
+    xs = [int(v) for v in rng.integers(0, 1 << 64, 400, dtype=np.uint64)]
+    half = 1 << (b - 1)
+    # ties at every level, with and without the next digit's top bit, carry ripples through digits of B - 1, the wrap at the top
+    for l in range(level):
+        sh = 64 - b * (l + 1)
+        xs += [(half << sh) & M64, ((half << sh) | (half << (sh + b))) & M64 if l else (half << sh) & M64, (((1 << b) - 1) << sh | (half << (sh - b) if sh >= b + r else 0)) & M64]
+    xs += [0, 1, M64, 1 << 63, (1 << 63) - 1, (1 << r) - 1 if r else 0, M64 - ((1 << (r - 1)) if r else 0) + 1 & M64]
+    same = 0
+    for x in xs:
+        d = [int(v) for v in orc.decompose_offset(x, b, level)]
+        assert d == _decompose_offset_restated(x, b, level)
+        assert all(-half <= v < half for v in d)
+        closest = ((((x >> r) + ((x >> (r - 1)) & 1)) << r) & M64) if r else x
+        assert sum(v << (64 - b * (l + 1)) for l, v in enumerate(d)) & M64 == closest
+        t = _decompose_restated(x, b, level) if r else None
+        if t is not None and all(abs(v) != half for v in t):
+            assert d == t
+            same += 1
+    assert same > 150
+
+
 def test_mod_switch():
     assert orc.mod_switch(0) == 0
     assert orc.mod_switch(1 << 54) == 1
@@ -87,7 +124,7 @@ def test_external_product_against_exact_arithmetic():
     got = orc.external_product_add(p, level, b, ggsw, d, acc0)
     want = acc0.copy()
     for r in range(k1):
-        digs = np.array([orc.decompose(int(x), b, level) for x in d[r]], dtype=np.int64)     # [512][level]
+        digs = np.array([orc.decompose_offset(int(x), b, level) for x in d[r]], dtype=np.int64)     # [512][level] (the external products' rule)
         for l in range(level):
             for c in range(k1):
                 want[c] += orc.negacyclic_mul_exact(digs[:, l], ggsw[l, r, c])

@@ -394,94 +394,62 @@ __device__ __forceinline__ void decompose_all(uint64_t x, int (&dig)[LEVELS])
     }
 }
 
-// Streaming form used by the external product: the first call consumes x and leaves a 32-bit
-// state; later calls peel one level each (least significant level first).  Requires
-// BASE_LOG*(LEVELS-1) <= 32.
+// ---- gadget decomposition of the EXTERNAL PRODUCTS (blind rotation, CMUX): canonical form v3 (round 5) ---------------------------
+// After the closest-representable rounding (x + 2^(R-1), R = 64 - BASE_LOG LEVELS: the same rounding as tfhe-rs' SignedDecomposer)
+// the digits are taken by the OFFSET rule of the original TFHE library (tGswTorus32PolynomialDecompH): with
+//     z = x_rounded + sum_l (B/2) 2^(64 - BASE_LOG (l + 1))            (one 64-bit addition resolves every carry)
+// digit_l = (bits [64 - BASE_LOG (l+1), 64 - BASE_LOG l) of z) - B/2, in [-B/2, B/2).  It recomposes to the same closest representable
+// value as the tfhe-rs rule (decompose_all above, which the key switches keep) and gives the same digits except where a digit is
+// exactly +-B/2: a tie always carries here, tfhe-rs lets the next digit's top bit decide.  Why: the sequential
+// rule costs five dependent integer instructions per digit; this one costs one (a signed bit-field extract of z), and the kernel
+// is bound by vector issue and by the socket's power cap, so instructions are time.  Same noise: |digit| <= B/2 either way.
 //
-// The tfhe-rs rule  d = st & (B-1); st >>= b; carry = (((d-1)|st)&d) >> (b-1); st += carry; d -= carry << b
-// says: carry iff d > B/2, or d == B/2 and the next digit's top bit is set.  With e = bit (2b-1) of the state that is
-// "d + (B/2 - 1) + e >= B", i.e. ONE addition whose overflow out of the low digit is the carry:
-//   t = st + (B/2 - 1) + e;   st' = t >> b;   digit = st - (st' << b)
-// (5 instructions per digit instead of 9; same digits for every input).
+// Streaming form: the first call consumes the rounded input and leaves the remaining (LEVELS - 1) BASE_LOG <= 32 bits of z in a
+// 32-bit state; later calls peel one level each, least significant level first.
+template <int BASE_LOG, int LEVELS>
+__device__ __forceinline__ constexpr uint64_t decompose_offset()
+{
+    uint64_t o = 0;
+    for (int l = 0; l < LEVELS; ++l) o += (1ull << (BASE_LOG - 1)) << (64 - BASE_LOG * (l + 1));
+    return o;
+}
+
 template <int BASE_LOG>
 __device__ __forceinline__ int decompose_next(uint32_t &state)
 {
-#ifdef FHE_PEEL_OLD
-    uint32_t d = state & ((1u << BASE_LOG) - 1);
-    uint32_t st = state >> BASE_LOG;
-    uint32_t carry = (((d - 1) | st) & d) >> (BASE_LOG - 1);
-    state = st + carry;
-    return (int)d - (int)(carry << BASE_LOG);
-#else
-    const uint32_t e = (state >> (2 * BASE_LOG - 1)) & 1u;
-    const uint32_t t = state + ((1u << (BASE_LOG - 1)) - 1u) + e;
-    const int digit = (int)(state - (t & ~((1u << BASE_LOG) - 1u)));
-    state = t >> BASE_LOG;
+    const int digit = (int)(state & ((1u << BASE_LOG) - 1u)) - (1 << (BASE_LOG - 1));
+    state >>= BASE_LOG;
     return digit;
-#endif
 }
 
 // First peel from xr = x + 2^(R-1) (the rounding addition already done by the caller, wrapping), R = 64 - BASE_LOG*LEVELS.
 template <int BASE_LOG, int LEVELS>
 __device__ __forceinline__ int decompose_first_rounded(uint64_t xr, uint32_t &state)
 {
+    static_assert(BASE_LOG * (LEVELS - 1) <= 32, "the remaining digits must fit the 32-bit state");
     constexpr int R = 64 - BASE_LOG * LEVELS;
-    const uint32_t d = (uint32_t)(xr >> R) & ((1u << BASE_LOG) - 1u);
-    if (LEVELS == 1) {
-        // no digit above this one: the tie d == B/2 stays +B/2
-        const uint32_t t = d + ((1u << (BASE_LOG - 1)) - 1u);
-        state = 0;
-        return (int)(d - (t & ~((1u << BASE_LOG) - 1u)));
-    }
-    const uint32_t st = (uint32_t)(xr >> (R + BASE_LOG));                          // the remaining LEVELS-1 digits (32 bits at most)
-    const uint32_t e = (st >> (BASE_LOG - 1)) & 1u;
-    const uint32_t t = d + ((1u << (BASE_LOG - 1)) - 1u) + e;
-    uint32_t s2 = st + (t >> BASE_LOG);
-    if (BASE_LOG * (LEVELS - 1) < 32) s2 &= (uint32_t)((1ULL << (BASE_LOG * (LEVELS - 1))) - 1);
-    state = s2;
-    return (int)(d - (t & ~((1u << BASE_LOG) - 1u)));
-}
-
-// ---- "z-form" of the same decomposition for BASE_LOG = 8, LEVELS = 5 (all carries resolved by ONE 64-bit addition) --------------
-// With y = the 40 kept bits of the rounded input (bytes b_0 .. b_4, least significant level first) and e_l = bit 7 of b_{l+1}
-// (e_4 = 0), the sequential rule above is "carry out of digit l iff b_l + carry_in + 127 + e_l >= 256": a tie (b_l + carry_in
-// == 128) is the only case in which e_l matters, and in a tie no carry has rippled into byte l + 1, so e_l may be read from the
-// RAW input.  Hence z = y + sum_l (127 + e_l) 256^l has every carry of the rule in it and
-//     digit_l = byte_l(z) - 127 - e_l          (two's complement, in [-128, 128]).
-// xr is the rounded input (x + 2^23, wrapping); its low 24 bits take no part (the constant has zeros there).
-// zform_first returns the least significant digit, leaves byte_1..4(z) in `state` and the three e-bits the later digits need
-// (e_1, e_2, e_3 at bits 0, 8, 16) in `ebits`; zform_next<SEL>(state, e) is digit SEL + 1.
-__device__ __forceinline__ int zform_first(uint64_t xr, uint32_t &state, uint32_t &ebits)
-{
-    const uint32_t xlo = (uint32_t)xr, xhi = (uint32_t)(xr >> 32);
-    const uint32_t eh = (xhi >> 15) & 0x00010101u;                  // e_1, e_2, e_3
-    const uint32_t e0 = (xhi << 17) & 0x01000000u;                  // e_0 = bit 7 of b_1, moved to bit 24
-    const uint32_t plo = 0x7F000000u + e0, phi = 0x7F7F7F7Fu + eh;
-    const uint64_t z = (((uint64_t)xhi << 32) | xlo) + (((uint64_t)phi << 32) | plo);
-    state = (uint32_t)(z >> 32);
-    ebits = eh;
-    return (int)((uint32_t)z >> 24) - (int)(plo >> 24);
-}
-template <int SEL>
-__device__ __forceinline__ int zform_next(uint32_t state, uint32_t e)
-{
-    return (int)((state >> (8 * SEL)) & 0xFFu) - 127 - (int)e;
+    const uint64_t z = xr + decompose_offset<BASE_LOG, LEVELS>();
+    state = LEVELS == 1 ? 0u : (uint32_t)(z >> (R + BASE_LOG));                  // exactly (LEVELS-1) BASE_LOG bits
+    return (int)((uint32_t)(z >> R) & ((1u << BASE_LOG) - 1u)) - (1 << (BASE_LOG - 1));
 }
 
 template <int BASE_LOG, int LEVELS>
 __device__ __forceinline__ int decompose_first(uint64_t x, uint32_t &state)
 {
-#ifdef FHE_PEEL_OLD
-    constexpr int R = 64 - BASE_LOG * LEVELS;
-    uint64_t y = (x >> R) + ((x >> (R - 1)) & 1);
-    uint32_t d = (uint32_t)y & ((1u << BASE_LOG) - 1);
-    uint32_t st;
-    if (LEVELS == 1) st = 0;
-    else st = (uint32_t)(y >> BASE_LOG) & (uint32_t)((1ULL << (BASE_LOG * (LEVELS - 1))) - 1);
-    uint32_t carry = (((d - 1) | st) & d) >> (BASE_LOG - 1);
-    state = st + carry;
-    return (int)d - (int)(carry << BASE_LOG);
-#else
     return decompose_first_rounded<BASE_LOG, LEVELS>(x + (1ULL << (64 - BASE_LOG * LEVELS - 1)), state);
-#endif
+}
+
+// The same digits for BASE_LOG = 8, LEVELS = 5 with the state kept as SIGNED bytes (z's upper word with the top bit of every byte
+// flipped: byte ^ 0x80 = byte - 128 mod 256), so that a digit is ONE signed bit-field extract at a (wave-uniform) bit offset and the
+// state is never shifted: decompose8x5_first returns the least significant digit (level 4), decompose8x5_at(state, 8 j) the digit of
+// level 3 - j.
+__device__ __forceinline__ int decompose8x5_first(uint64_t xr, uint32_t &state)
+{
+    const uint64_t z = xr + decompose_offset<8, 5>();
+    state = (uint32_t)(z >> 32) ^ 0x80808080u;
+    return (int)((uint32_t)z ^ 0x80000000u) >> 24;
+}
+__device__ __forceinline__ int decompose8x5_at(uint32_t state, unsigned bit)
+{
+    return __builtin_amdgcn_sbfe((int)state, bit, 8u);
 }

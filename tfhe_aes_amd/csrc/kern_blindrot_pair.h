@@ -53,12 +53,6 @@
                                 spread over half a pass, instead of behind the twiddle multiplies / inside the last stage only: the LDS store path
                                 (13 cycles per ds_write_b128, one path per CU) is what the eight wavefronts of a unit queue for in that stretch */
 #endif
-#ifndef BRP_ZFORM
-#define BRP_ZFORM 0          /* gadget decomposition: 0 = streaming peel (fft_dev.h decompose_next, 5 integer instructions per digit); 2 = z-form (fft_dev.h
-                                zform_first / zform_next: one 64-bit addition resolves every carry, a digit is a byte of the sum minus 127 minus a tie bit),
-                                the tie bits of a lane's 32 coefficients packed in four registers; 1 = z-form WITHOUT the tie bits (every tie rounds up:
-                                digits differ from the reference rule on ties only -- a timing proxy, not a product mode) */
-#endif
 #define BRP_HALF_TILES (EP_GROUPS - 1)                                                   /* 15 tiles per half: group 15 shares group 14's */
 #define BRP_LDS_DOUBLES(R) (2 * FHE_TW_ENTRIES + 2 * BRP_HALF_TILES * GROUP_TILE_DOUBLES + ((R) == 3 ? 6 * FHE_N : 0))   /* R = 3: 159,488 B */
 #define BRP_PARK_WORDS_PER_HALF (BRP_RESIDENT_HI ? 8 * EP_THREADS * 2 : 16 * EP_THREADS * 2)   /* per half and iteration: 32 KB (lo[] only) or 64 KB */
@@ -187,10 +181,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 
         // ---- d = acc * X^t - acc; first (least significant) digit ---------------------------------------------------------------
         uint32_t st_lo[16], st_hi[16];
-#if BRP_ZFORM
-        static_assert(BASE_LOG == 8 && LEVELS == 5, "the z-form is written for five levels of eight bits");
-        uint32_t epk[4] = {0, 0, 0, 0};
-#endif
+        static_assert(BASE_LOG == 8 && LEVELS == 5, "the signed-byte decomposition state is written for five levels of eight bits");
         double xr[16], xi[16];
         double2 w0[8], w1[8];
         EP_STAMP(11);
@@ -216,21 +207,8 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                 k0[0] = (uint32_t)RND - m0; k0[1] = 0; k1[0] = (uint32_t)RND - m1; k1[1] = 0;
                 const uint64_t x0 = (__builtin_bit_cast(uint64_t, x0w) + lo[a]) + __builtin_bit_cast(uint64_t, k0);
                 const uint64_t x1 = (__builtin_bit_cast(uint64_t, x1w) + hi[a]) + __builtin_bit_cast(uint64_t, k1);
-#if BRP_ZFORM
-                {
-                    uint32_t e_lo, e_hi;
-                    xr[a] = (double)zform_first(x0, st_lo[a], e_lo);
-                    xi[a] = (double)zform_first(x1, st_hi[a], e_hi);
-#if BRP_ZFORM == 2
-                    // coefficient i = 2a (+ 1): tie bits at bit (i % 8) + {0, 8, 16} of epk[i / 8]
-                    if ((2 * a) % 8 == 0) epk[(2 * a) / 8] = e_lo; else epk[(2 * a) / 8] |= e_lo << ((2 * a) % 8);
-                    epk[(2 * a + 1) / 8] |= e_hi << ((2 * a + 1) % 8);
-#endif
-                }
-#else
-                xr[a] = (double)decompose_first_rounded<BASE_LOG, LEVELS>(x0, st_lo[a]);
-                xi[a] = (double)decompose_first_rounded<BASE_LOG, LEVELS>(x1, st_hi[a]);
-#endif
+                xr[a] = (double)decompose8x5_first(x0, st_lo[a]);
+                xi[a] = (double)decompose8x5_first(x1, st_hi[a]);
                 if ((a & (EP_ROT_CHUNK - 1)) == EP_ROT_CHUNK - 1) __builtin_amdgcn_sched_barrier(0);
             }
             wave_lds_sync();
@@ -511,32 +489,16 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 #endif
             }
             __builtin_amdgcn_sched_barrier(0);
-#if BRP_ZFORM
-            // the next digit is the low byte of the state; the state and the packed tie bits move down one byte per level (the level
-            // loop is rolled: a byte select by level would need a branch, and branches here cost the register allocator its footing)
-#pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                uint32_t e0 = 0, e1 = 0;
-#if BRP_ZFORM == 2
-                e0 = (epk[(2 * a) / 8] >> ((2 * a) % 8)) & 1u;
-                e1 = (epk[(2 * a + 1) / 8] >> ((2 * a + 1) % 8)) & 1u;
-#endif
-                xr[a] = (double)zform_next<0>(st_lo[a], e0);
-                xi[a] = (double)zform_next<0>(st_hi[a], e1);
-                st_lo[a] >>= 8; st_hi[a] >>= 8;
-            }
-#if BRP_ZFORM == 2
-#pragma unroll
-            for (int k = 0; k < 4; ++k) epk[k] >>= 8;
-#endif
-#elif defined(BRP_ABL_NOPEEL)
+#ifdef BRP_ABL_NOPEEL
 #pragma unroll
             for (int a = 0; a < 16; ++a) { xr[a] = (double)(int)st_lo[a]; xi[a] = (double)(int)st_hi[a]; }
 #else
+            // the digits of level l - 1: signed byte LEVELS - 1 - l of the state (one bit-field extract at a wave-uniform offset each)
+            const unsigned dbit = 8u * (unsigned)(LEVELS - 1 - l);
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
-                xr[a] = (double)decompose_next<BASE_LOG>(st_lo[a]);
-                xi[a] = (double)decompose_next<BASE_LOG>(st_hi[a]);
+                xr[a] = (double)decompose8x5_at(st_lo[a], dbit);
+                xi[a] = (double)decompose8x5_at(st_hi[a], dbit);
             }
 #endif
             EP_STAMP(1);

@@ -22,7 +22,6 @@ VARIANTS = {
     "base": [],
     # ---- round 5: quarter-wise last stages (stores spread over half a pass), z-form decomposition, per-lever proxies ----
     "q0": ["-DBRP_QUARTERS=0"], "q1_c2": ["-DBRP_CHUNK=2"], "q1_c4": ["-DBRP_CHUNK=4"], "q0_stamps": ["-DBRP_QUARTERS=0", "-DEP_STAMPS"],
-    "z1": ["-DBRP_ZFORM=1"], "z2": ["-DBRP_ZFORM=2"],
     "noxstore": ["-DBRP_ABL_NOXSTORE"], "nodstore": ["-DBRP_ABL_NODSTORE"], "nostores": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NODSTORE"],
     "noxread": ["-DBRP_ABL_NOXREAD"], "noxpose": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NOXREAD"], "nolds_fwd": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NOXREAD", "-DBRP_ABL_NODSTORE"],
     "nobar": ["-DBRP_ABL_NOBAR"], "nobar_skew0": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=0"], "nobar_skew40": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=40"],
@@ -65,7 +64,7 @@ VARIANTS = {
     # ---- one workgroup per CU (extra LDS) ----
     "b16_one_wg": ["-DBR16_PAD_DOUBLES=2048"], "b16_one_wg_stamps": ["-DBR16_PAD_DOUBLES=2048", "-DEP_STAMPS"],
     # ---- knobs ----
-    "oldpeel": ["-DFHE_PEEL_OLD"], "oldconv": ["-DFHE_TORUS_CONV_OLD"],
+    "oldconv": ["-DFHE_TORUS_CONV_OLD"],
     "nochunk": ["-DFFT_CHUNK_BARRIERS=0"], "chunk1": ["-DFFT_CHUNK=1"], "chunk2": ["-DFFT_CHUNK=2"], "chunk8": ["-DFFT_CHUNK=8"],
     "b16_prio1": ["-DBR16_MAC_PRIO=1"], "b16_xprio0": ["-DFFT_XPOSE_PRIO=0"],
     "rot2": ["-DEP_ROT_CHUNK=2"], "rot8": ["-DEP_ROT_CHUNK=8"], "rot16": ["-DEP_ROT_CHUNK=16"],
