@@ -267,7 +267,7 @@ class Engine:
         """the blind-rotation kernel this context really launches for a batch of `bits` (after the occupancy fallbacks) and its cut"""
         form, um, rm, ut, rt = _c.c_int(), _c.c_uint64(), _c.c_uint32(), _c.c_uint64(), _c.c_uint32()
         name = _c.create_string_buffer(96)
-        self._check(self.lib.fheaes_k2_context_plan(self.h, bits, _c.byref(form), _c.byref(um), _c.byref(rm), _c.byref(ut), _c.byref(rt), name, len(name)))
+        self._check(self._lib.fheaes_k2_context_plan(self._h, bits, _c.byref(form), _c.byref(um), _c.byref(rm), _c.byref(ut), _c.byref(rt), name, len(name)))
         return {"form": form.value, "kernel": name.value.decode(), "units_main": um.value, "r_main": rm.value,
                 "units_tail": ut.value, "r_tail": rt.value}
 

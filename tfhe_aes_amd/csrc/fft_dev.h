@@ -347,6 +347,23 @@ __device__ __forceinline__ void nega_inv(double (&xr)[16], double (&xi)[16], con
 // double (checked against the definition on the CPU, 6e7 values around the tie / wrap / tiny cases).
 // torus_acc(acc, v) = acc + torus_from_double(v).
 typedef uint32_t fhe_u32x2 __attribute__((ext_vector_type(2)));
+// torus_acc_scaled(acc, w): the same with w = v * 2^-72 already formed by the caller.  The scaling by a power of two commutes with every
+// rounding of the inverse transform's last constant multiply (no result is anywhere near the subnormal range), so a caller may fold
+// it into those constants: cmulc(x, 2^-72 c) == 2^-72 cmulc(x, c) bit for bit.
+__device__ __forceinline__ uint64_t torus_acc_scaled(uint64_t acc, double w)
+{
+    w -= __builtin_rint(w);
+    const double C_HI = 0x1.8p20, C_LO = 0x1.8p-12;
+    const double mh = w + C_HI;
+    const double hf = mh - C_HI;
+    const double lt = w - hf;
+    const double ml = lt + C_LO;
+    const fhe_u32x2 bh = __builtin_bit_cast(fhe_u32x2, mh), bl = __builtin_bit_cast(fhe_u32x2, ml);
+    fhe_u32x2 r;
+    r[0] = bl[0];
+    r[1] = bh[0] + bl[1] + 0xC0C80000u;
+    return acc + __builtin_bit_cast(uint64_t, r);
+}
 __device__ __forceinline__ uint64_t torus_acc(uint64_t acc, double v)
 {
 #ifdef FHE_TORUS_CONV_OLD

@@ -48,7 +48,7 @@
 #define BRP_CHUNK 1          /* butterflies issued together in this kernel's transforms (fft_dev.h dft16; 1 / 2 / 4 / 8: 211.5 / 214.4 / 214.2 / 223.4 ms) */
 #endif
 #ifndef BRP_QUARTERS
-#define BRP_QUARTERS 1       /* 1: the last two stages of both passes of a forward transform are issued quarter by quarter (fft_dev.h dft16_quarters), and
+#define BRP_QUARTERS 0       /* 1: the last two stages of both passes of a forward transform are issued quarter by quarter (fft_dev.h dft16_quarters), and
                                 the LDS stores of a pass's results -- the transpose's 16, the transformed digits' 16 -- leave from inside those quarters,
                                 spread over half a pass, instead of behind the twiddle multiplies / inside the last stage only: the LDS store path
                                 (13 cycles per ds_write_b128, one path per CU) is what the eight wavefronts of a unit queue for in that stretch */
@@ -566,18 +566,20 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 #endif
         }
         dft16<true, false, BRP_CHUNK>(xr, xi);
+        // conj psi^(16a) with the back-conversion's 2^-72 folded into the constants (exact: a power of two commutes with the roundings)
+        xr[0] *= 0x1p-72; xi[0] *= 0x1p-72;
 #pragma unroll
-        for (int a = 1; a < 16; ++a) cmulc(xr[a], xi[a], FHE_PSI16_RE[a], FHE_PSI16_IM[a]);
+        for (int a = 1; a < 16; ++a) cmulc(xr[a], xi[a], FHE_PSI16_RE[a] * 0x1p-72, FHE_PSI16_IM[a] * 0x1p-72);
         EP_STAMP(9);
         wave_lds_sync();
 #pragma unroll
         for (int a = 0; a < 16; ++a) {
 #if BRP_RESIDENT_HI
-            lo[a] = torus_acc(pkl[a], -xr[a]);
-            hi[a] = torus_acc(hi[a], -xi[a]);
+            lo[a] = torus_acc_scaled(pkl[a], -xr[a]);
+            hi[a] = torus_acc_scaled(hi[a], -xi[a]);
 #else
-            lo[a] = torus_acc(pk[a].x, -xr[a]);
-            hi[a] = torus_acc(pk[a].y, -xi[a]);
+            lo[a] = torus_acc_scaled(pk[a].x, -xr[a]);
+            hi[a] = torus_acc_scaled(pk[a].y, -xi[a]);
 #endif
             stage_park(a, tq);
             if ((a & 1) == 1) __builtin_amdgcn_sched_barrier(0);

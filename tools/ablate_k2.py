@@ -21,7 +21,7 @@ from tfhe_aes_amd.client import Client  # noqa: E402
 VARIANTS = {
     "base": [],
     # ---- round 5: quarter-wise last stages (stores spread over half a pass), z-form decomposition, per-lever proxies ----
-    "q0": ["-DBRP_QUARTERS=0"], "q1_c2": ["-DBRP_CHUNK=2"], "q1_c4": ["-DBRP_CHUNK=4"], "q0_stamps": ["-DBRP_QUARTERS=0", "-DEP_STAMPS"],
+    "q1": ["-DBRP_QUARTERS=1"], "q0": ["-DBRP_QUARTERS=0"], "q1_c2": ["-DBRP_CHUNK=2"], "q1_c4": ["-DBRP_CHUNK=4"], "q0_stamps": ["-DBRP_QUARTERS=0", "-DEP_STAMPS"],
     "noxstore": ["-DBRP_ABL_NOXSTORE"], "nodstore": ["-DBRP_ABL_NODSTORE"], "nostores": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NODSTORE"],
     "noxread": ["-DBRP_ABL_NOXREAD"], "noxpose": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NOXREAD"], "nolds_fwd": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NOXREAD", "-DBRP_ABL_NODSTORE"],
     "nobar": ["-DBRP_ABL_NOBAR"], "nobar_skew0": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=0"], "nobar_skew40": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=40"],
