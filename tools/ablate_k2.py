@@ -124,6 +124,8 @@ def main():
             subprocess.run(cmd, check=True, capture_output=True)
         lib = ctypes.CDLL(str(so))
         for fn, (res, args) in _native.SIGNATURES.items():
+            if not hasattr(lib, fn):                    # an older library (so:...) may lack entry points added since
+                continue
             f = getattr(lib, fn)
             f.restype, f.argtypes = res, args
         h = ctypes.c_void_p()
