@@ -135,97 +135,6 @@ __device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], Hook h
     FFT_SWAP(1, 8) FFT_SWAP(2, 4) FFT_SWAP(3, 12) FFT_SWAP(5, 10) FFT_SWAP(7, 14) FFT_SWAP(11, 13)
 #undef FFT_SWAP
 }
-// One chunk of NB butterflies of stage `st` (0..3) of dft16's radix-2 DIT network, butterfly numbers idx[0..NB-1] (0..7): the same
-// three steps and the same operations as inside dft16 (first fma of every u, second fma, then every v), on the same registers.
-template <bool INV, bool OFFSET, int NB>
-__device__ __forceinline__ void dft16_butterflies(double (&xr)[16], double (&xi)[16], const int st, const int (&idx)[NB])
-{
-    constexpr int BR[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-    const int n = 2 << st, half = n / 2;
-    double tr[NB], ti[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int i = idx[j], blk = (i / half) * n, k = i % half;
-        const int e = OFFSET ? (64 * k + 16) / n : 64 * k / n;
-        const int P = BR[blk + k], Q = BR[blk + k + half];
-        if (e != 0 && e != 16) {
-            const double c = FHE_PSI16_RE[e];
-            tr[j] = __builtin_fma(c, xr[Q], xr[P]);
-            ti[j] = __builtin_fma(c, xi[Q], xi[P]);
-        }
-    }
-    if (FFT_CHUNK_BARRIERS) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int i = idx[j], blk = (i / half) * n, k = i % half;
-        const int e = OFFSET ? (64 * k + 16) / n : 64 * k / n;
-        const int Q = BR[blk + k + half];
-        if (e != 0 && e != 16) {
-            const double s = INV ? -FHE_PSI16_IM[e] : FHE_PSI16_IM[e];
-            tr[j] = __builtin_fma(-s, xi[Q], tr[j]);
-            ti[j] = __builtin_fma(s, xr[Q], ti[j]);
-        }
-    }
-    if (FFT_CHUNK_BARRIERS) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int i = idx[j], blk = (i / half) * n, k = i % half;
-        const int e = OFFSET ? (64 * k + 16) / n : 64 * k / n;
-        const int P = BR[blk + k], Q = BR[blk + k + half];
-        const double pr = xr[P], pi = xi[P], qr = xr[Q], qi = xi[Q];
-        if (e == 0) {
-            xr[P] = pr + qr; xi[P] = pi + qi; xr[Q] = pr - qr; xi[Q] = pi - qi;
-        } else if (e == 16) {
-            if (!INV) { xr[P] = pr - qi; xi[P] = pi + qr; xr[Q] = pr + qi; xi[Q] = pi - qr; }
-            else      { xr[P] = pr + qi; xi[P] = pi - qr; xr[Q] = pr - qi; xi[Q] = pi + qr; }
-        } else {
-            xr[Q] = __builtin_fma(2.0, pr, -tr[j]);
-            xi[Q] = __builtin_fma(2.0, pi, -ti[j]);
-            xr[P] = tr[j]; xi[P] = ti[j];
-        }
-    }
-    if (FFT_CHUNK_BARRIERS) __builtin_amdgcn_sched_barrier(0);
-}
-
-// dft16 with its last two stages issued QUARTER by quarter (same butterflies, same operations, same results: only the order in which
-// independent butterflies are issued differs).  Stage-3 butterfly k needs the stage-2 outputs at positions k and k + 8, which the
-// stage-2 butterflies k mod 4 and 4 + k mod 4 produce: quarter q = stage-2 butterflies {q, q + 4}, then stage-3 butterflies {q, q + 4},
-// after which the outputs q, q + 4, q + 8, q + 12 are final (in registers fft_reg(.): NO renaming to natural order at the end --
-// the caller consumes them from inside `quarter_hook(q)`).  A caller spreads the LDS stores of a transform's results over half of
-// the transform instead of issuing them behind its last stage.  `hook(stage)` runs after stages 0 and 1.
-template <bool INV, bool OFFSET, int CHUNK = FFT_CHUNK, typename Hook = FftNoHook, typename QuarterHook = FftNoHook>
-__device__ __forceinline__ void dft16_quarters(double (&xr)[16], double (&xi)[16], Hook hook = Hook(), QuarterHook quarter_hook = QuarterHook())
-{
-    static_assert(CHUNK == 1 || CHUNK == 2 || CHUNK == 4 || CHUNK == 8, "butterflies per chunk");
-    static_assert(!(INV && OFFSET), "the inverse applies its untwist after the transform");
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-#pragma unroll
-        for (int c0 = 0; c0 < 8; c0 += CHUNK) {
-            int idx[CHUNK];
-#pragma unroll
-            for (int j = 0; j < CHUNK; ++j) idx[j] = c0 + j;
-            dft16_butterflies<INV, OFFSET, CHUNK>(xr, xi, st, idx);
-        }
-        hook(st);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int st = 2; st < 4; ++st) {
-            if (CHUNK == 1) {
-                const int i0[1] = {q}, i1[1] = {q + 4};
-                dft16_butterflies<INV, OFFSET, 1>(xr, xi, st, i0);
-                dft16_butterflies<INV, OFFSET, 1>(xr, xi, st, i1);
-            } else {
-                const int i2[2] = {q, q + 4};
-                dft16_butterflies<INV, OFFSET, 2>(xr, xi, st, i2);
-            }
-        }
-        quarter_hook(q);
-    }
-}
-
 // LDS visibility between the lanes of ONE wavefront (a group never spans wavefronts).
 __device__ __forceinline__ void wave_lds_sync()
 {

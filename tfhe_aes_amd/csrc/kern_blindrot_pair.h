@@ -47,12 +47,6 @@
 #ifndef BRP_CHUNK
 #define BRP_CHUNK 1          /* butterflies issued together in this kernel's transforms (fft_dev.h dft16; 1 / 2 / 4 / 8: 211.5 / 214.4 / 214.2 / 223.4 ms) */
 #endif
-#ifndef BRP_QUARTERS
-#define BRP_QUARTERS 0       /* 1: the last two stages of both passes of a forward transform are issued quarter by quarter (fft_dev.h dft16_quarters), and
-                                the LDS stores of a pass's results -- the transpose's 16, the transformed digits' 16 -- leave from inside those quarters,
-                                spread over half a pass, instead of behind the twiddle multiplies / inside the last stage only: the LDS store path
-                                (13 cycles per ds_write_b128, one path per CU) is what the eight wavefronts of a unit queue for in that stretch */
-#endif
 #define BRP_HALF_TILES (EP_GROUPS - 1)                                                   /* 15 tiles per half: group 15 shares group 14's */
 #define BRP_LDS_DOUBLES(R) (2 * FHE_TW_ENTRIES + 2 * BRP_HALF_TILES * GROUP_TILE_DOUBLES + ((R) == 3 ? 6 * FHE_N : 0))   /* R = 3: 159,488 B */
 #define BRP_PARK_WORDS_PER_HALF (BRP_RESIDENT_HI ? 8 * EP_THREADS * 2 : 16 * EP_THREADS * 2)   /* per half and iteration: 32 KB (lo[] only) or 64 KB */
@@ -190,9 +184,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             const int bq_ = tq & 15;
             uint64_t *stage = stage_of(tq);
             wave_lds_sync();
-#if !BRP_QUARTERS
             fft_tw_load8(w0, tw, bq_, FHE_TW_STRIDE);
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
@@ -251,84 +243,6 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
-#if BRP_QUARTERS
-            constexpr int NE = BRP_EARLY, NHOOK = 7, NT = BRP_TAIL;
-            auto early = [&](const int h) { key_rows(NE * h / NHOOK, NE * (h + 1) / NHOOK); };
-            // the table column, just in time: quarter q of pass 1 multiplies by the entries k1 = q, q + 8, q + 4, q + 12 (w0[q], w1[q], w0[q + 4],
-            // w1[q + 4]); the entries of quarters 0 and 1 are requested here (the first two stages hide the LDS round trip), those of
-            // quarter q + 2 behind quarter q, into the registers that quarter has just left: eight entries (32 registers) live at most
-            auto table_quarter = [&](const int q) {
-                w0[q] = tw[q * FHE_TW_STRIDE + bq_]; w1[q] = tw[(q + 8) * FHE_TW_STRIDE + bq_];
-                w0[q + 4] = tw[(q + 4) * FHE_TW_STRIDE + bq_]; w1[q + 4] = tw[(q + 12) * FHE_TW_STRIDE + bq_];
-            };
-            table_quarter(0);
-            table_quarter(1);
-            __builtin_amdgcn_sched_barrier(0);
-            dft16_quarters<false, true, BRP_CHUNK>(xr, xi,
-                [&](const int stage) {
-                    if (stage != 1) return;
-                    __builtin_amdgcn_sched_barrier(0);
-                    EP_STAMP(2);
-#ifndef BRP_ABL_NOBAR
-                    if (tiles_busy) wg_barrier_lds_only();        // every thread of BOTH halves is done reading the previous level's digits
-#endif
-                    EP_STAMP(3);
-#if FFT_XPOSE_PRIO
-                    __builtin_amdgcn_s_setprio(FFT_XPOSE_PRIO);
-#endif
-                },
-                [&](const int q) {
-                    // outputs q, q + 8 (butterfly q) and q + 4, q + 12 (butterfly q + 4) of pass 1 are final: twiddle, transpose store
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k1 = q + 8 * (j & 1) + 4 * (j >> 1), c = fft_reg(k1);
-                        if (k1 < 8) cmul(xr[c], xi[c], w0[k1].x, w0[k1].y); else cmul(xr[c], xi[c], w1[k1 - 8].x, w1[k1 - 8].y);
-                        double2 v; v.x = xr[c]; v.y = xi[c];
-#ifndef BRP_ABL_NOXSTORE
-                        *reinterpret_cast<double2 *>(tile + 2 * (k1 * 17 + bq_)) = v;
-#else
-                        asm volatile("" :: "v"(v.x), "v"(v.y));   // timing proxy: the values are computed, the store is not issued
-#endif
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (q < 2) { table_quarter(q + 2); __builtin_amdgcn_sched_barrier(0); }
-                    if (NE) early(q);
-                });
-            wave_lds_sync();
-#ifndef BRP_ABL_NOXREAD
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int c = fft_reg(q);
-                double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
-                xr[c] = v.x; xi[c] = v.y;
-            }
-#endif
-            if (NE) { __builtin_amdgcn_sched_barrier(0); early(4); }
-#if FFT_XPOSE_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            dft16_quarters<false, false, BRP_CHUNK>(xr, xi,
-                [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(5 + stage); } },
-                [&](const int q) {
-                    // the transformed digits q, q + 8, q + 4, q + 12 leave for the tile (registers fft_reg(.): dft16_quarters does not rename)
-                    if (q == 0) wave_lds_sync();
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k2 = q + 8 * (j & 1) + 4 * (j >> 1);
-                        double2 v; v.x = xr[fft_reg(k2)]; v.y = xi[fft_reg(k2)];
-#ifndef BRP_ABL_NODSTORE
-                        *reinterpret_cast<double2 *>(tile + 2 * (bq_ + 16 * k2)) = v;
-#else
-                        asm volatile("" :: "v"(v.x), "v"(v.y));
-#endif
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    {
-                        constexpr int NL = NQ - NE - NT;
-                        key_rows(NE + NL * q / 4, NE + NL * (q + 1) / 4);
-                    }
-                });
-#else
 #if !BRP_W1_LATE
             fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE);
 #endif
@@ -361,18 +275,24 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 #endif
                     if (k1 < 8) cmul(xr[k1], xi[k1], w0[k1].x, w0[k1].y); else cmul(xr[k1], xi[k1], w1[k1 - 8].x, w1[k1 - 8].y);
                     double2 v; v.x = xr[k1]; v.y = xi[k1];
+#ifndef BRP_ABL_NOXSTORE
                     *reinterpret_cast<double2 *>(tile + 2 * (k1 * 17 + bq_)) = v;
+#else
+                    asm volatile("" :: "v"(v.x), "v"(v.y));      // timing proxy: the values are computed, the store is not issued
+#endif
                     if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                     if (NE && k1 == 7) { __builtin_amdgcn_sched_barrier(0); early(0); }
                 }
                 if (NE) { __builtin_amdgcn_sched_barrier(0); early(1); }
                 wave_lds_sync();
+#ifndef BRP_ABL_NOXREAD
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int c = fft_reg(q);
                     double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
                     xr[c] = v.x; xi[c] = v.y;
                 }
+#endif
                 if (NE) { __builtin_amdgcn_sched_barrier(0); early(2); }
 #if FFT_XPOSE_PRIO
                 __builtin_amdgcn_s_setprio(0);
@@ -387,7 +307,11 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                                             for (int h = 0; h < 2; ++h) {
                                                 const int k2 = c0 + j + 8 * h;
                                                 double2 v; v.x = xr[fft_reg(k2)]; v.y = xi[fft_reg(k2)];
+#ifndef BRP_ABL_NODSTORE
                                                 *reinterpret_cast<double2 *>(tile + 2 * (bq_ + 16 * k2)) = v;
+#else
+                                                asm volatile("" :: "v"(v.x), "v"(v.y));
+#endif
                                             }
                                         }
                                         __builtin_amdgcn_sched_barrier(0);
@@ -398,7 +322,6 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                                         }
                                     });
             }
-#endif
             EP_STAMP(4);
             __builtin_amdgcn_sched_barrier(0);
             EP_STAMP(5);
@@ -484,9 +407,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             level_body(l, l != LEVELS - 1, std::false_type{});
             {
                 const int tq = brp_opaque_tid() & 255;
-#if !BRP_QUARTERS
                 fft_tw_load8(w0, tw, tq & 15, FHE_TW_STRIDE);
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
 #ifdef BRP_ABL_NOPEEL

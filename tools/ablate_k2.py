@@ -21,15 +21,13 @@ from tfhe_aes_amd.client import Client  # noqa: E402
 VARIANTS = {
     "base": [],
     # ---- round 5: quarter-wise last stages (stores spread over half a pass), z-form decomposition, per-lever proxies ----
-    "q1": ["-DBRP_QUARTERS=1"], "q0": ["-DBRP_QUARTERS=0"], "q1_c2": ["-DBRP_CHUNK=2"], "q1_c4": ["-DBRP_CHUNK=4"], "q0_stamps": ["-DBRP_QUARTERS=0", "-DEP_STAMPS"],
     "noxstore": ["-DBRP_ABL_NOXSTORE"], "nodstore": ["-DBRP_ABL_NODSTORE"], "nostores": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NODSTORE"],
     "noxread": ["-DBRP_ABL_NOXREAD"], "noxpose": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NOXREAD"], "nolds_fwd": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NOXREAD", "-DBRP_ABL_NODSTORE"],
     "nobar": ["-DBRP_ABL_NOBAR"], "nobar_skew0": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=0"], "nobar_skew40": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=40"],
     "nobar_skew80": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=80"], "nobar_skew160": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=160"],
-    "q0_nobar_skew0": ["-DBRP_QUARTERS=0", "-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=0"], "q0_nobar_skew80": ["-DBRP_QUARTERS=0", "-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=80"], "nopeel": ["-DBRP_ABL_NOPEEL"], "noload": ["-DBR16_ABL_NOLOAD"], "nopark": ["-DBR16_ABL_NOPARK"],
+ "nopeel": ["-DBRP_ABL_NOPEEL"], "noload": ["-DBR16_ABL_NOLOAD"], "nopark": ["-DBR16_ABL_NOPARK"],
     "nostores_noload": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NODSTORE", "-DBR16_ABL_NOLOAD"],
     "all6": ["-DK2_PAIR_TAIL4=0"],
-    "q1_e7": ["-DBRP_EARLY=7"], "q1_e11": ["-DBRP_EARLY=11"], "q1_t2": ["-DBRP_TAIL=2"], "q1_t6": ["-DBRP_TAIL=6"], "q1_xp0": ["-DFFT_XPOSE_PRIO=0"],
     # ---- round 4: parking ----
     "nohome": ["-DBR16_W3_LDS_HOME=0"],                                   # wavefront 3 parks like the others (idle lanes still skip)
     "r3park": ["-DBR16_W3_LDS_HOME=0", "-DBR16_PARK_OWNERS_ONLY=0"],      # round-3 behaviour: every lane parks
