@@ -136,8 +136,8 @@ void orc_get_twiddles(double *psi_interleaved /* [512][2] */)
  *       = sum_b e^{2 pi i b k2 / 16} . T[k1][b] . sum_a z_{16a+b} e^{2 pi i a (k1 + 1/4) / 16}
  * with T[k1][b] = e^{2 pi i b (k1 + 1/4) / 256} = psi^(b (4 k1 + 1)):
  *   pass 1  DFT16 over a with frequency offset 1/4 (radix-2 DIT; stage n uses e^{2 pi i (k + 1/4)/n}: constants),
- *   pass 2  plain DFT16 over b (radix-2 DIT; twiddles 1 and +-i are additions) whose FIRST stage takes its inputs multiplied by
- *           T[k1][b] (form v3, round 5: folded into the butterfly, see dft16_rows_fwd_twiddled; v2 multiplied in a pass of its own).
+ *   then    multiply by T[k1][b] (cmul, all 256 entries),
+ *   pass 2  plain DFT16 over b (radix-2 DIT; twiddles 1 and +-i are additions).
  * Inverse: plain conjugate DFT16 over k2, multiply by conj T[k1][b] (b >= 1), plain conjugate DFT16 over k1,
  * multiply by conj psi^(16a) (a >= 1).
  * DIT butterfly with a non-trivial twiddle w = (c, s), 6 fused operations:
@@ -194,62 +194,18 @@ static void transpose16(double x[16][16])
     for (int a = 0; a < 16; ++a) for (int b = a + 1; b < 16; ++b) { double t = x[a][b]; x[a][b] = x[b][a]; x[b][a] = t; }
 }
 
-/* Pass 2 of the FORWARD transform (canonical form v3): plain DFT16 over the first index of x[b][k1] with the inter-pass twiddle
- * T[k1][b] folded into its FIRST radix-2 stage.  That stage pairs rows (b, b + 8), b in bit-reversed order 0, 4, 2, 6, 1, 5, 3, 7:
- *   t = T[k1][b] x_b            cmul: tr = fma(pr, wr, -(pi wi)); ti = fma(pr, wi, pi wr)      (b = 0: T = 1, t = x_0)
- *   u = t + T[k1][b+8] x_{b+8}  ur = fma(-qi, wi', fma(qr, wr', tr)); ui = fma(qi, wr', fma(qr, wi', ti))
- *   v = 2 t - u                 vr = fma(2, tr, -ur); vi = fma(2, ti, -ui)
- * (10 fused operations per butterfly instead of two complex multiplies and four additions); stages 2..4 as in dft16_rows. */
-static void dft16_rows_fwd_twiddled(double xr[16][16], double xi[16][16])
-{
-    double tr[16][16], ti[16][16];
-    for (int m = 0; m < 8; ++m) {
-        int bP = BITREV4[2 * m], bQ = BITREV4[2 * m + 1];              /* bQ = bP + 8 */
-        for (int col = 0; col < 16; ++col) {                           /* col = k1 */
-            double pr = xr[bP][col], pi = xi[bP][col], qr = xr[bQ][col], qi = xi[bQ][col];
-            double t1r = pr, t1i = pi;
-            if (bP != 0) {
-                double wr = TW_RE[col][bP], wi = TW_IM[col][bP];
-                t1r = fma(pr, wr, -(pi * wi));
-                t1i = fma(pr, wi, pi * wr);
-            }
-            double wr = TW_RE[col][bQ], wi = TW_IM[col][bQ];
-            double ur = fma(-qi, wi, fma(qr, wr, t1r));
-            double ui = fma(qi, wr, fma(qr, wi, t1i));
-            tr[2 * m][col] = ur; ti[2 * m][col] = ui;
-            tr[2 * m + 1][col] = fma(2.0, t1r, -ur); ti[2 * m + 1][col] = fma(2.0, t1i, -ui);
-        }
-    }
-    for (int n = 4; n <= 16; n <<= 1) {
-        int half = n / 2;
-        for (int blk = 0; blk < 16; blk += n) for (int k = 0; k < half; ++k) {
-            int e = 64 * k / n;
-            double c = PSI_RE[16 * e], s = PSI_IM[16 * e];
-            int P = blk + k, Q = P + half;
-            for (int col = 0; col < 16; ++col) {
-                double pr = tr[P][col], pi = ti[P][col], qr = tr[Q][col], qi = ti[Q][col];
-                double ur, ui, vr, vi;
-                if (e == 0) { ur = pr + qr; ui = pi + qi; vr = pr - qr; vi = pi - qi; }
-                else if (e == 16) { ur = pr - qi; ui = pi + qr; vr = pr + qi; vi = pi - qr; }
-                else {
-                    ur = fma(-s, qi, fma(c, qr, pr));
-                    ui = fma(s, qr, fma(c, qi, pi));
-                    vr = fma(2.0, pr, -ur);
-                    vi = fma(2.0, pi, -ui);
-                }
-                tr[P][col] = ur; ti[P][col] = ui; tr[Q][col] = vr; ti[Q][col] = vi;
-            }
-        }
-    }
-    memcpy(xr, tr, sizeof tr); memcpy(xi, ti, sizeof ti);
-}
-
 /* in: z[16a+b] (untwisted fold); out: X[k] natural order, X_k = sum_j z_j e^{+2 pi i j(k+1/4)/256} */
 static void fft256_fwd(double zr[16][16], double zi[16][16])
 {
     dft16_rows(zr, zi, 0, 1);                                /* [k1][b] */
+    for (int k1 = 0; k1 < 16; ++k1) for (int b = 0; b < 16; ++b) {
+        double wr = TW_RE[k1][b], wi = TW_IM[k1][b];
+        double xr = zr[k1][b], xi = zi[k1][b];
+        zr[k1][b] = fma(xr, wr, -(xi * wi));
+        zi[k1][b] = fma(xr, wi, xi * wr);
+    }
     transpose16(zr); transpose16(zi);                        /* [b][k1] */
-    dft16_rows_fwd_twiddled(zr, zi);                         /* [k2][k1] = X[k1+16k2]; multiplies by T[k1][b] on the way in */
+    dft16_rows(zr, zi, 0, 0);                                /* [k2][k1] = X[k1+16k2] */
 }
 
 /* in: X[k] natural; out: z[16a+b] = sum_k X_k e^{-2 pi i j(k+1/4)/256} (unscaled; the untwist is included) */

@@ -9,9 +9,8 @@
 //   z_j = p_j + i p_{j+256}, j = 16a + b (lane b);  X_k = sum_j z_j e^{2 pi i j (k + 1/4)/256}, k = k1 + 16 k2
 //   pass 1   DFT16 over a with frequency offset 1/4 (radix-2 DIT; the stage twiddles e^{2 pi i (k + 1/4)/n} are the SAME in every
 //            lane: compile-time constants, no table read -- the negacyclic twist costs no pass of its own),
-//   pass 2   transpose, plain DFT16 over b (radix-2 DIT, twiddles 1 and +-i are additions) whose FIRST stage takes its inputs
-//            multiplied by the twiddle T[k1][b] = psi^(b (4 k1 + 1)) (the one table, a ROW of 16 entries per lane), folded into the
-//            butterfly (form v3, round 5: 10 fused operations instead of two complex multiplies + four additions).
+//   twiddle  T[k1][b] = psi^(b (4 k1 + 1)) (cmul; the one table, 16 entries per lane, read a whole pass ahead),
+//   pass 2   transpose, plain DFT16 over b (radix-2 DIT, twiddles 1 and +-i are additions).
 //   inverse  plain conjugate DFT16, conj T, transpose, plain conjugate DFT16, conj psi^(16a) (constants).
 // Non-trivial DIT butterfly, 6 fused operations:  u = p + w q as two fma per component, v = 2p - u as one.
 // No contraction beyond the written fma (the translation unit is compiled with -ffp-contract=off).
@@ -70,14 +69,14 @@ __device__ __forceinline__ constexpr int fft_reg(int k)       // register that h
 {
     return ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | ((k & 8) >> 3);
 }
-template <bool INV, bool OFFSET, int CHUNK = FFT_CHUNK, typename Hook = FftNoHook, typename ChunkHook = FftNoChunkHook, int FIRST = 0>
+template <bool INV, bool OFFSET, int CHUNK = FFT_CHUNK, typename Hook = FftNoHook, typename ChunkHook = FftNoChunkHook>
 __device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], Hook hook = Hook(), ChunkHook chunk_hook = ChunkHook())
 {
     static_assert(CHUNK == 1 || CHUNK == 2 || CHUNK == 4 || CHUNK == 8, "butterflies per chunk");
     static_assert(!(INV && OFFSET), "the inverse applies its untwist after the transform");
     constexpr int BR[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};   // logical position -> register
 #pragma unroll
-    for (int st = FIRST; st < 4; ++st) {
+    for (int st = 0; st < 4; ++st) {
         const int n = 2 << st, half = n / 2;
         // The eight butterflies of a stage, FFT_CHUNK at a time, each chunk in three steps (first fma of every u, second fma,
         // then every v): a dependent f64 instruction issues 8 cycles after its producer, and a wave that has the SIMD to itself
@@ -136,34 +135,6 @@ __device__ __forceinline__ void dft16(double (&xr)[16], double (&xi)[16], Hook h
     FFT_SWAP(1, 8) FFT_SWAP(2, 4) FFT_SWAP(3, 12) FFT_SWAP(5, 10) FFT_SWAP(7, 14) FFT_SWAP(11, 13)
 #undef FFT_SWAP
 }
-// First stage of the FORWARD transform's pass 2 with the inter-pass twiddle folded in (canonical form v3, oracle
-// dft16_rows_fwd_twiddled): the lane holds x_b (b = 0..15, natural order) of frequency k1 = its lane index and the table ROW
-// w0[b] = T[k1][b], w1[b] = T[k1][b + 8].  Butterfly (b, b + 8), b in the order 0, 4, 2, 6, 1, 5, 3, 7 (dft16's stage 0):
-//   t = T_b x_b (b = 0: t = x_0);  u = t + T_{b+8} x_{b+8};  v = 2 t - u        (10 fused operations)
-// `hook(i)` runs after butterfly i = 0..7 (a caller interleaves table reads / key loads).  dft16<false, false, ..., FIRST = 1> follows.
-template <typename Hook = FftNoHook>
-__device__ __forceinline__ void dft16_stage0_twiddled(double (&xr)[16], double (&xi)[16], const double2 (&w0)[8], const double2 (&w1)[8], Hook hook = Hook())
-{
-    constexpr int BR[16] = {0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int P = BR[2 * i], Q = P + 8;
-        double tr = xr[P], ti = xi[P];
-        if (P != 0) {
-            const double m0 = xi[P] * w0[P].y, m1 = xi[P] * w0[P].x;
-            tr = __builtin_fma(xr[P], w0[P].x, -m0);
-            ti = __builtin_fma(xr[P], w0[P].y, m1);
-        }
-        const double ur = __builtin_fma(-xi[Q], w1[P].y, __builtin_fma(xr[Q], w1[P].x, tr));
-        const double ui = __builtin_fma(xi[Q], w1[P].x, __builtin_fma(xr[Q], w1[P].y, ti));
-        xr[Q] = __builtin_fma(2.0, tr, -ur);
-        xi[Q] = __builtin_fma(2.0, ti, -ui);
-        xr[P] = ur; xi[P] = ui;
-        if (FFT_CHUNK_BARRIERS) __builtin_amdgcn_sched_barrier(0);
-        hook(i);
-    }
-}
-
 // LDS visibility between the lanes of ONE wavefront (a group never spans wavefronts).
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -218,7 +189,13 @@ __device__ __forceinline__ void fft_tw_mul(double *xr, double *xi, const double2
         if (!CONJ) cmul(xr[k], xi[k], w[k].x, w[k].y); else cmulc(xr[k], xi[k], w[k].x, w[k].y);
     }
 }
-// the table ROW of lane k1: w0 = T[k1][0..7], w1 = T[k1][8..15] (forward pass 2's first stage; the inverse's conj T, entry 0 unused)
+// the forward transform's table column of lane b: w0 = T[0..7][b], w1 = T[8..15][b]
+__device__ __forceinline__ void fft_fwd_table(double2 (&w0)[8], double2 (&w1)[8], const double2 *tw, int b)
+{
+    fft_tw_load8(w0, tw, b, FHE_TW_STRIDE);
+    fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + b, FHE_TW_STRIDE);
+}
+// the inverse transform's table row of lane k1: w0 = T[k1][0..7] (entry 0 unused), w1 = T[k1][8..15]
 __device__ __forceinline__ void fft_inv_table(double2 (&w0)[8], double2 (&w1)[8], const double2 *tw, int k1)
 {
     fft_tw_load8(w0, tw, FHE_TW_STRIDE * k1, 1);
@@ -227,27 +204,29 @@ __device__ __forceinline__ void fft_inv_table(double2 (&w0)[8], double2 (&w1)[8]
 
 // Forward negacyclic transform.  In: xr[a] = p[16a+b], xi[a] = p[256+16a+b] (already doubles), lane b.
 // Out: lane k1 (= b) holds X[k1 + 16*k2] in (xr[k2], xi[k2]).
-// Split in two halves: the head (pass 1) touches only registers; the tail is the first to write the group's tile (a caller may put a
-// workgroup barrier between them) and consumes the table ROW of the lane (w0 = T[lane][0..7], w1 = T[lane][8..15]: fft_inv_table).
-__device__ __forceinline__ void nega_fwd_head(double (&xr)[16], double (&xi)[16])
+// Split in two halves: the head touches only registers (and the table entries the caller has read with fft_fwd_table), the
+// tail is the first to write the group's tile (a caller may put a workgroup barrier between them).
+__device__ __forceinline__ void nega_fwd_head(double (&xr)[16], double (&xi)[16], const double2 (&w0)[8], const double2 (&w1)[8])
 {
     dft16<false, true>(xr, xi);
+    __builtin_amdgcn_sched_barrier(0);
+    fft_tw_mul<false, 8>(xr, xi, w0);
+    fft_tw_mul<false, 8>(xr + 8, xi + 8, w1);
 }
 
-__device__ __forceinline__ void nega_fwd_tail(double (&xr)[16], double (&xi)[16], double *tile, int b, const double2 (&w0)[8], const double2 (&w1)[8])
+__device__ __forceinline__ void nega_fwd_tail(double (&xr)[16], double (&xi)[16], double *tile, int b)
 {
     group_transpose(xr, xi, tile, b);
-    dft16_stage0_twiddled(xr, xi, w0, w1);
-    dft16<false, false, FFT_CHUNK, FftNoHook, FftNoChunkHook, 1>(xr, xi);
+    dft16<false, false>(xr, xi);
 }
 
 __device__ __forceinline__ void nega_fwd(double (&xr)[16], double (&xi)[16], const double2 *tw, double *tile, int b)
 {
     double2 w0[8], w1[8];
-    fft_inv_table(w0, w1, tw, b);
+    fft_fwd_table(w0, w1, tw, b);
     __builtin_amdgcn_sched_barrier(0);
-    nega_fwd_head(xr, xi);
-    nega_fwd_tail(xr, xi, tile, b, w0, w1);
+    nega_fwd_head(xr, xi, w0, w1);
+    nega_fwd_tail(xr, xi, tile, b);
 }
 
 // Inverse (unscaled).  In: lane k1 holds F[k1 + 16*k2] in index k2.

@@ -28,15 +28,28 @@
 #define BR16_MAC_PRIO 0
 #endif
 #ifndef BR16_EARLY
-#define BR16_EARLY 9       /* GGSW entries (of 25 per level; scaled to K1*K1) requested between the butterflies of pass 2 (7 hooks).  Round 5 (table
-                              row consumed by pass 2's first stage): more than 9 spill (10: 2 registers, 12: 6-10, 15: 14); rounds 2-4 (table column
-                              consumed before the transpose) ran 15 here. */
+#define BR16_EARLY 15      /* GGSW entries (of 25 per level; scaled to K1*K1) requested between the instructions of the transform's
+                              second half.  Measured at 16,384 bits: 0 -> 267 ms, 12 -> 267, 13 -> 255, 14 -> 253, 15 -> 251.5, 16 -> 263,
+                              20 -> 268, 25 -> 297 (spills past 18); some of them ahead of the tiles-free barrier, or the late ones
+                              between the digit stores: no gain. */
+#endif
+#ifndef BR16_XPOSE_IN_TWIDDLE
+#define BR16_XPOSE_IN_TWIDDLE 1    /* with BR16_STORE_IN_PASS2: 239 -> 231 ms per 16,384-bit launch; either one alone: no change */
 #endif
 #ifndef BR16_STAGE_AT_END
 #define BR16_STAGE_AT_END 1
 #endif
 #ifndef BR16_HEAD
 #define BR16_HEAD 0        /* GGSW entries (of 25 per level) requested between the stages of pass 1 */
+#endif
+#ifndef BR16_LATE_IN_PASS2
+#define BR16_LATE_IN_PASS2 1
+#endif
+#ifndef BR16_READ_IN_PASS2
+#define BR16_READ_IN_PASS2 1
+#endif
+#ifndef BR16_STORE_IN_PASS2
+#define BR16_STORE_IN_PASS2 1
 #endif
 #ifndef BR16_PARK_AUX_ST
 #define BR16_PARK_AUX_ST 0 /* cache policy bits of the parking stores (1 = sc0, 2 = nt, 16 = sc1; measured: see DESIGN.md) */
@@ -64,6 +77,9 @@
 #endif
 #ifndef BR16_MAC_TAIL
 #define BR16_MAC_TAIL (BR16_RESIDENT_HI ? 5 : 0)   /* GGSW entries (of 25 per level) requested only after the multiply-accumulate has used row 0 */
+#endif
+#ifndef BR16_W1_LATE
+#define BR16_W1_LATE BR16_RESIDENT_HI
 #endif
 #define BR16_HOME_LDS_DOUBLES (2 * FHE_TW_ENTRIES + (EP_GROUPS - 1) * GROUP_TILE_DOUBLES + 3 * FHE_N)   /* table + 15 tiles + 3 accumulators = 81,920 B */
 
@@ -207,22 +223,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
         // ---- accumulator -> tile and parking slab; d = acc * X^t - acc; first (least significant) digit -----------
         uint32_t st_lo[16], st_hi[16];
         double xr[16], xi[16];
-        // The table ROW of this lane (w0[b] = T[lane][b], w1[b] = T[lane][b + 8]; fft_dev.h dft16_stage0_twiddled) in three requests, in the
-        // order stage 0 of pass 2 consumes it (butterflies (b, b + 8), b = 0, 4, 2, 6, 1, 5, 3, 7): seven entries a decomposition step + pass 1
-        // ahead, four behind the transposed reads, the last four from inside stage 0 (kern_blindrot_pair.h does the same)
-        double2 w0[8], w1[8];
-        auto table_first = [&](const int lane) {
-            const double2 *row = tw + FHE_TW_STRIDE * lane;
-            w1[0] = row[8]; w0[4] = row[4]; w1[4] = row[12]; w0[2] = row[2]; w1[2] = row[10]; w0[6] = row[6]; w1[6] = row[14];
-        };
-        auto table_second = [&](const int lane) {
-            const double2 *row = tw + FHE_TW_STRIDE * lane;
-            w0[1] = row[1]; w1[1] = row[9]; w0[5] = row[5]; w1[5] = row[13];
-        };
-        auto table_third = [&](const int lane) {
-            const double2 *row = tw + FHE_TW_STRIDE * lane;
-            w0[3] = row[3]; w1[3] = row[11]; w0[7] = row[7]; w1[7] = row[15];
-        };
+        double2 w0[8], w1[8];                                     // twiddle buffers
         EP_STAMP(11);
         {
             const int tq = br16_opaque_tid();
@@ -233,7 +234,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             for (int a = 0; a < 16; ++a) stage_park(a, tq);
 #endif
             wave_lds_sync();
-            table_first(bq_);                                     // first seven entries of the lane's table ROW: land during the rotation
+            fft_tw_load8(w0, tw, bq_, FHE_TW_STRIDE);             // first half of the lane's table column (T[0..7][b]): lands during the rotation
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
@@ -295,32 +296,68 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            // ---- forward transform (fft_dev.h, canonical form v3): pass 1 (frequency offset 1/4, constants only), transpose, pass 2 whose
-            //      first stage multiplies by the lane's table row (read a decomposition step ago / behind the transposed reads) ------
+            // ---- forward transform (fft_dev.h): pass 1 (frequency offset 1/4, constants only), twiddle by the table column read a
+            //      whole decomposition step ago, transpose, pass 2 ---------------------------------------------------------------
+#if !BR16_W1_LATE
+            fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE);   // second half of the column (T[8..15][b]): lands during pass 1
+#endif
             __builtin_amdgcn_sched_barrier(0);
-            // pass 1 is pure vector work (192 fused operations, no table): the first BR16_HEAD GGSW entries are requested between its stages
+            // pass 1 is pure vector work (192 fused operations, no table): the first BR16_HEAD GGSW entries are requested between its
+            // stages, as many as the register file has room for while the table column and the working set are both live
             constexpr int NH = BR16_HEAD * K1 * K1 / 25;
+#ifndef BR16_ABL_NOFFT
             dft16<false, true>(xr, xi, [&](const int stage) { if (NH) { __builtin_amdgcn_sched_barrier(0); key_rows(NH * stage / 4, NH * (stage + 1) / 4); } });
+#else
+            key_rows(0, NH);
+#endif
             __builtin_amdgcn_sched_barrier(0);
+#if !BR16_XPOSE_IN_TWIDDLE
+            fft_tw_mul<false, 8>(xr, xi, w0);
+            fft_tw_mul<false, 8>(xr + 8, xi + 8, w1);
+#endif
             EP_STAMP(2);
-            // The first BR16_EARLY entries are requested a few at a time BETWEEN the butterflies of pass 2, into the registers the table
-            // entries have just left: a burst of 25 loads blocks the in-order wave for as long as the L1 takes to accept them
-            // (~150 cycles each with one workgroup per CU); spaced out, the same acceptance time passes under the wave's own vector work.
+            // The first BR16_EARLY entries are requested a few at a time BETWEEN the instructions of the transpose and of the
+            // second DFT16, into the registers the twiddle buffers have just left: a burst of 25 loads blocks the in-order
+            // wave for as long as the L1 takes to accept them (~150 cycles each with one workgroup per CU); spaced out,
+            // the same acceptance time passes under the wave's own LDS and vector work.
             constexpr int NE = BR16_EARLY * K1 * K1 / 25 > NH ? BR16_EARLY * K1 * K1 / 25 : NH, NHOOK = 7;
             constexpr int NT = BR16_MAC_TAIL * K1 * K1 / 25;    // the last NT entries (of the last rows) are requested from inside the multiply-accumulate
             auto early = [&](const int h) { key_rows(NH + (NE - NH) * h / NHOOK, NH + (NE - NH) * (h + 1) / NHOOK); };
             if (tiles_busy) wg_barrier_lds_only();                // every thread is done reading the previous level's digits
             EP_STAMP(3);
+#if defined(BR16_ABL_NOFFT)
+            group_transpose(xr, xi, tile, bq_);
+            key_rows(0, NE);
+#elif defined(BR16_ABL_NOXPOSE)
+            dft16<false, false>(xr, xi);
+            key_rows(0, NE);
+#else
             {
 #if FFT_XPOSE_PRIO
                 __builtin_amdgcn_s_setprio(FFT_XPOSE_PRIO);
 #endif
 #pragma unroll
                 for (int k1 = 0; k1 < 16; ++k1) {
+#if BR16_W1_LATE
+                    // the second half of the table column is requested only now (it lands during the first eight multiplies): while pass 1
+                    // runs the registers hold one half of the column, not both
+                    if (k1 == 0) { fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE); __builtin_amdgcn_sched_barrier(0); }
+#endif
+#if BR16_XPOSE_IN_TWIDDLE
+                    // each value leaves for the transpose tile as soon as its twiddle multiply is done: 16 stores spread over 64
+                    // vector instructions instead of a burst
+                    if (k1 < 8) cmul(xr[k1], xi[k1], w0[k1].x, w0[k1].y); else cmul(xr[k1], xi[k1], w1[k1 - 8].x, w1[k1 - 8].y);
+#endif
                     double2 v; v.x = xr[k1]; v.y = xi[k1];
                     *reinterpret_cast<double2 *>(tile + 2 * (k1 * 17 + bq_)) = v;
+#if BR16_XPOSE_IN_TWIDDLE
+                    if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#endif
+                    if (NE && k1 == 7) { __builtin_amdgcn_sched_barrier(0); early(0); }
                 }
+                if (NE) { __builtin_amdgcn_sched_barrier(0); early(1); }
                 wave_lds_sync();
+#if BR16_READ_IN_PASS2 && BR16_STORE_IN_PASS2
                 // transposed reads in the order the first butterfly stage consumes them (registers fft_reg(0), fft_reg(1), ...), and
                 // NO wait behind them: the butterflies start as the pairs arrive.  The group's reads must all have been issued and
                 // returned before its first digit store reuses the tile: that wait sits in front of that store (stage 3), by when it is free.
@@ -330,43 +367,66 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
                     double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
                     xr[c] = v.x; xi[c] = v.y;
                 }
-                table_second(bq_);
-                __builtin_amdgcn_sched_barrier(0);
+                if (NE) { __builtin_amdgcn_sched_barrier(0); early(2); }
+#else
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
+                    xr[c] = v.x; xi[c] = v.y;
+                }
+                if (NE) { __builtin_amdgcn_sched_barrier(0); early(2); }
+                wave_lds_sync();
+#endif
 #if FFT_XPOSE_PRIO
                 __builtin_amdgcn_s_setprio(0);
 #endif
-                dft16_stage0_twiddled(xr, xi, w0, w1, [&](const int i) {
-                    if (i == 1) { table_third(bq_); __builtin_amdgcn_sched_barrier(0); }
-                    if (NE && i >= 2 && (i & 1) == 0) { __builtin_amdgcn_sched_barrier(0); early(i / 2 - 1); }      // i = 2, 4, 6: hooks 0, 1, 2
-                });
-                if (NE) { __builtin_amdgcn_sched_barrier(0); early(3); }
+#if BR16_STORE_IN_PASS2
                 // the transformed digits leave for the tile as the last butterfly stage produces them (outputs k and k + 8 of butterfly
                 // k), instead of as a burst of 16 stores behind the transform: the LDS queue is what the waves of a CU wait for most
-                auto stage_hook = [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } };   // stages 1..3: hooks 4..6
-                auto store_hook = [&](const int stage, const int c0) {
-                    if (stage != 3) return;
-                    if (c0 == 0) wave_lds_sync();      // every lane of the group has its transposed values (see the reads)
+                dft16<false, false>(xr, xi, [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } },
+                                    [&](const int stage, const int c0) {
+                                        if (stage != 3) return;
+#if BR16_READ_IN_PASS2
+                                        if (c0 == 0) wave_lds_sync();      // every lane of the group has its transposed values (see the reads)
+#endif
 #pragma unroll
-                    for (int j = 0; j < FFT_CHUNK; ++j) {
+                                        for (int j = 0; j < FFT_CHUNK; ++j) {
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const int k2 = c0 + j + 8 * h;
-                            double2 v; v.x = xr[fft_reg(k2)]; v.y = xi[fft_reg(k2)];
-                            *reinterpret_cast<double2 *>(tile + 2 * (bq_ + 16 * k2)) = v;
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    // ... and the registers of the values just stored take the next share of the remaining GGSW entries
-                    {
-                        constexpr int NL = K1 * K1 - NE - NT, PARTS = 8 / FFT_CHUNK;
-                        const int part = c0 / FFT_CHUNK;
-                        key_rows(NE + NL * part / PARTS, NE + NL * (part + 1) / PARTS);
-                    }
-                };
-                dft16<false, false, FFT_CHUNK, decltype(stage_hook), decltype(store_hook), 1>(xr, xi, stage_hook, store_hook);
+                                            for (int h = 0; h < 2; ++h) {
+                                                const int k2 = c0 + j + 8 * h;
+                                                double2 v; v.x = xr[fft_reg(k2)]; v.y = xi[fft_reg(k2)];
+                                                *reinterpret_cast<double2 *>(tile + 2 * (bq_ + 16 * k2)) = v;
+                                            }
+                                        }
+                                        __builtin_amdgcn_sched_barrier(0);
+#if BR16_LATE_IN_PASS2
+                                        // ... and the registers of the values just stored take the next share of the remaining GGSW entries
+                                        {
+                                            constexpr int NL = K1 * K1 - NE - NT, PARTS = 8 / FFT_CHUNK;
+                                            const int part = c0 / FFT_CHUNK;
+                                            key_rows(NE + NL * part / PARTS, NE + NL * (part + 1) / PARTS);
+                                        }
+#endif
+                                    });
+#else
+                dft16<false, false>(xr, xi, [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } });
+#endif
             }
+#endif
             EP_STAMP(4);
+            // store the transformed digits, then request the remaining GGSW entries of this level into the registers the
+            // working set has just left
+#if !BR16_STORE_IN_PASS2 || defined(BR16_ABL_NOFFT) || defined(BR16_ABL_NOXPOSE)
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) {
+                double2 v; v.x = xr[k2]; v.y = xi[k2];
+                *reinterpret_cast<double2 *>(tile + 2 * (bq_ + 16 * k2)) = v;
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
+#if !(BR16_LATE_IN_PASS2 && BR16_STORE_IN_PASS2) || defined(BR16_ABL_NOFFT) || defined(BR16_ABL_NOXPOSE)
+            key_rows(NE, K1 * K1 - NT);
+#endif
             EP_STAMP(5);
             wg_barrier_lds_only();                                // digits of all groups visible; key loads stay in flight
             EP_STAMP(6);
@@ -448,7 +508,7 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             level_body(l, l != LEVELS - 1, std::false_type{});
             {
                 const int tq = br16_opaque_tid();
-                table_first(tq & 15);                             // lands during the decomposition step
+                fft_tw_load8(w0, tw, tq & 15, FHE_TW_STRIDE);     // lands during the decomposition step
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -484,7 +544,8 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
         // inverse transform (fft_dev.h's nega_inv, the table row read a pass ahead)
         dft16<true, false>(xr, xi);
         __builtin_amdgcn_sched_barrier(0);
-        // every value leaves for the transpose tile as soon as its twiddle multiply is done
+#if BR16_XPOSE_IN_TWIDDLE
+        // as in the forward transform: every value leaves for the transpose tile as soon as its twiddle multiply is done
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             if (c >= 1) { if (c < 8) cmulc(xr[c], xi[c], w0[c].x, w0[c].y); else cmulc(xr[c], xi[c], w1[c - 8].x, w1[c - 8].y); }
@@ -499,6 +560,12 @@ __device__ __forceinline__ void blind_rotate16_unit(const ExtProdArgs &A, double
             double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
             xr[c] = v.x; xi[c] = v.y;
         }
+#else
+        fft_tw_mul<true, 8>(xr, xi, w0, 1);
+        fft_tw_mul<true, 8>(xr + 8, xi + 8, w1);
+        __builtin_amdgcn_sched_barrier(0);
+        group_transpose(xr, xi, tile, bq_);
+#endif
         if (home_wave) {
             // wavefront 3 of a HOME unit: the old accumulator comes from its LDS home (the lane's own coefficients: written by this
             // lane, no synchronisation needed), landing during the transform's last pass

@@ -154,12 +154,12 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
         if (transform) {
             double xr[16], xi[16];
             double2 w0[8], w1[8];
-            fft_inv_table(w0, w1, tw, bq_);            // the lane's table ROW (pass 2's first stage): lands during the coefficient reads and the first pass
+            fft_fwd_table(w0, w1, tw, bq_);            // lands during the coefficient reads and the first pass
 #pragma unroll
             for (int a = 0; a < 16; ++a) { xr[a] = tile[16 * a + bq_]; xi[a] = tile[256 + 16 * a + bq_]; }
             wave_lds_sync();                           // the group's lanes have their coefficients before the transform reuses the tile
-            nega_fwd_head(xr, xi);
-            nega_fwd_tail(xr, xi, tile, bq_, w0, w1);
+            nega_fwd_head(xr, xi, w0, w1);
+            nega_fwd_tail(xr, xi, tile, bq_);
             EP_STAMP(2);
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) {

@@ -37,6 +37,10 @@
 #ifndef BRP_RESIDENT_HI
 #define BRP_RESIDENT_HI 1
 #endif
+#ifndef BRP_W1_LATE
+#define BRP_W1_LATE 2           /* 1: second half of the table column requested at the start of the twiddle pass; 2: in two requests of four entries, each
+                                into registers the first half has just left (no spill with hi[] resident: 249 VGPRs) */
+#endif
 #ifndef BRP_MAC_PRIO
 #define BRP_MAC_PRIO 1       /* wave priority during the multiply-accumulate (0 / 1 / 3: 214.2 / 211.8 / 212.0 ms per 16,384-bit launch) */
 #endif
@@ -173,30 +177,14 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
         uint32_t st_lo[16], st_hi[16];
         static_assert(BASE_LOG == 8 && LEVELS == 5, "the signed-byte decomposition state is written for five levels of eight bits");
         double xr[16], xi[16];
-        // The table ROW of this lane (w0[b] = T[lane][b], w1[b] = T[lane][b + 8]; fft_dev.h dft16_stage0_twiddled) in three requests, in the
-        // order stage 0 of pass 2 consumes it (butterflies (b, b + 8), b = 0, 4, 2, 6, 1, 5, 3, 7): the first seven entries a whole
-        // decomposition step + pass 1 ahead, four behind the transposed reads, the last four from inside stage 0 into registers its first
-        // butterflies have left -- the registers never hold the whole row beside the working set and the key entries in flight
         double2 w0[8], w1[8];
-        auto table_first = [&](const int lane) {
-            const double2 *row = tw + FHE_TW_STRIDE * lane;
-            w1[0] = row[8]; w0[4] = row[4]; w1[4] = row[12]; w0[2] = row[2]; w1[2] = row[10]; w0[6] = row[6]; w1[6] = row[14];
-        };
-        auto table_second = [&](const int lane) {
-            const double2 *row = tw + FHE_TW_STRIDE * lane;
-            w0[1] = row[1]; w1[1] = row[9]; w0[5] = row[5]; w1[5] = row[13];
-        };
-        auto table_third = [&](const int lane) {
-            const double2 *row = tw + FHE_TW_STRIDE * lane;
-            w0[3] = row[3]; w1[3] = row[11]; w0[7] = row[7]; w1[7] = row[15];
-        };
         EP_STAMP(11);
         {
             const int tq = brp_opaque_tid() & 255;
             const int bq_ = tq & 15;
             uint64_t *stage = stage_of(tq);
             wave_lds_sync();
-            table_first(bq_);
+            fft_tw_load8(w0, tw, bq_, FHE_TW_STRIDE);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < 16; ++a) {
@@ -255,14 +243,67 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
+#if !BRP_W1_LATE
+            fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             dft16<false, true, BRP_CHUNK>(xr, xi);
             __builtin_amdgcn_sched_barrier(0);
             EP_STAMP(2);
             constexpr int NE = BRP_EARLY, NHOOK = 7, NT = BRP_TAIL;
             auto early = [&](const int h) { key_rows(NE * h / NHOOK, NE * (h + 1) / NHOOK); };
-            auto stage_hook = [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } };   // stages 1..3: hooks 4..6
-            auto store_hook = [&](const int stage, const int c0) {
+#ifndef BRP_ABL_NOBAR
+            if (tiles_busy) wg_barrier_lds_only();                // every thread of BOTH halves is done reading the previous level's digits
+#endif
+            EP_STAMP(3);
+            {
+#if FFT_XPOSE_PRIO
+                __builtin_amdgcn_s_setprio(FFT_XPOSE_PRIO);
+#endif
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1) {
+#if BRP_W1_LATE == 1
+                    if (k1 == 0) { fft_tw_load8(w1, tw, 8 * FHE_TW_STRIDE + bq_, FHE_TW_STRIDE); __builtin_amdgcn_sched_barrier(0); }
+#elif BRP_W1_LATE == 2
+                    // the second half of the table column in two requests of four entries, each into registers the first half has just left
+                    if (k1 == 3 || k1 == 7) {
+                        const int e0 = k1 == 3 ? 0 : 4;
+#pragma unroll
+                        for (int e = e0; e < e0 + 4; ++e) w1[e] = tw[(8 + e) * FHE_TW_STRIDE + bq_];
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
+#ifdef BRP_ABL_FEWCMUL
+                    if (k1 % 3 != 0 || k1 == 0)      // timing proxy: 5 of the 16 twiddle multiplies (20 of a transform's 404 f64 instructions) left out
+#endif
+                    {
+                        if (k1 < 8) cmul(xr[k1], xi[k1], w0[k1].x, w0[k1].y); else cmul(xr[k1], xi[k1], w1[k1 - 8].x, w1[k1 - 8].y);
+                    }
+                    double2 v; v.x = xr[k1]; v.y = xi[k1];
+#ifndef BRP_ABL_NOXSTORE
+                    *reinterpret_cast<double2 *>(tile + 2 * (k1 * 17 + bq_)) = v;
+#else
+                    asm volatile("" :: "v"(v.x), "v"(v.y));      // timing proxy: the values are computed, the store is not issued
+#endif
+                    if ((k1 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                    if (NE && k1 == 7) { __builtin_amdgcn_sched_barrier(0); early(0); }
+                }
+                if (NE) { __builtin_amdgcn_sched_barrier(0); early(1); }
+                wave_lds_sync();
+#ifndef BRP_ABL_NOXREAD
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int c = fft_reg(q);
+                    double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
+                    xr[c] = v.x; xi[c] = v.y;
+                }
+#endif
+                if (NE) { __builtin_amdgcn_sched_barrier(0); early(2); }
+#if FFT_XPOSE_PRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
+                dft16<false, false, BRP_CHUNK>(xr, xi, [&](const int stage) { if (NE) { __builtin_amdgcn_sched_barrier(0); early(3 + stage); } },
+                                    [&](const int stage, const int c0) {
                                         if (stage != 3) return;
                                         if (c0 == 0) wave_lds_sync();
 #pragma unroll
@@ -284,47 +325,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                                             const int part = c0 / BRP_CHUNK;
                                             key_rows(NE + NL * part / PARTS, NE + NL * (part + 1) / PARTS);
                                         }
-                                    };
-#ifndef BRP_ABL_NOBAR
-            if (tiles_busy) wg_barrier_lds_only();                // every thread of BOTH halves is done reading the previous level's digits
-#endif
-            EP_STAMP(3);
-            {
-#if FFT_XPOSE_PRIO
-                __builtin_amdgcn_s_setprio(FFT_XPOSE_PRIO);
-#endif
-                // pass 1's results leave for the transpose tile as they are (form v3: the twiddle is folded into pass 2's first stage)
-#pragma unroll
-                for (int k1 = 0; k1 < 16; ++k1) {
-                    double2 v; v.x = xr[k1]; v.y = xi[k1];
-#ifndef BRP_ABL_NOXSTORE
-                    *reinterpret_cast<double2 *>(tile + 2 * (k1 * 17 + bq_)) = v;
-#else
-                    asm volatile("" :: "v"(v.x), "v"(v.y));      // timing proxy: the values are computed, the store is not issued
-#endif
-                }
-                wave_lds_sync();
-#ifndef BRP_ABL_NOXREAD
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int c = fft_reg(q);
-                    double2 v = *reinterpret_cast<const double2 *>(tile + 2 * (bq_ * 17 + c));
-                    xr[c] = v.x; xi[c] = v.y;
-                }
-#endif
-                table_second(bq_);
-                __builtin_amdgcn_sched_barrier(0);
-#if FFT_XPOSE_PRIO
-                __builtin_amdgcn_s_setprio(0);
-#endif
-                // stage 0 with the twiddle folded in; the key entries that used to go out between the transpose's instructions go out
-                // between its butterflies, into the registers the table entries leave
-                dft16_stage0_twiddled(xr, xi, w0, w1, [&](const int i) {
-                    if (i == 1) { table_third(bq_); __builtin_amdgcn_sched_barrier(0); }
-                    if (NE && i >= 2 && (i & 1) == 0) { __builtin_amdgcn_sched_barrier(0); early(i / 2 - 1); }      // i = 2, 4, 6: hooks 0, 1, 2
-                });
-                if (NE) { __builtin_amdgcn_sched_barrier(0); early(3); }
-                dft16<false, false, BRP_CHUNK, decltype(stage_hook), decltype(store_hook), 1>(xr, xi, stage_hook, store_hook);
+                                    });
             }
             EP_STAMP(4);
             __builtin_amdgcn_sched_barrier(0);
@@ -411,7 +412,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
             level_body(l, l != LEVELS - 1, std::false_type{});
             {
                 const int tq = brp_opaque_tid() & 255;
-                table_first(tq & 15);
+                fft_tw_load8(w0, tw, tq & 15, FHE_TW_STRIDE);
             }
             __builtin_amdgcn_sched_barrier(0);
 #ifdef BRP_ABL_NOPEEL

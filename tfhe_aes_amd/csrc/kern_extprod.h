@@ -226,16 +226,18 @@ __global__ __launch_bounds__(EP_THREADS, EP_MIN_WAVES) void extprod_rotate_kerne
             // first half of the transform needs no tile; the barrier that frees the tiles (other threads
             // may still be reading the previous level's digits) sits as late as possible
 #ifndef ABL_NO_FFT
-            double2 w0[8], w1[8];
-            fft_inv_table(w0, w1, tw, b);            // the table ROW of this lane, consumed by the tail's first stage
-            nega_fwd_head(xr, xi);
+            {
+                double2 w0[8], w1[8];
+                fft_fwd_table(w0, w1, tw, b);
+                nega_fwd_head(xr, xi, w0, w1);
+            }
 #endif
 #ifdef EP_LATE_BARRIER
             if (tiles_busy) __syncthreads();
 #endif
             EP_STAMP(2);
 #ifndef ABL_NO_FFT
-            nega_fwd_tail(xr, xi, tile, b, w0, w1);
+            nega_fwd_tail(xr, xi, tile, b);
 #endif
             EP_STAMP(4);
             const double2 *Gl = G + (size_t)l * K1 * K1 * FHE_H + tid;
