@@ -369,11 +369,14 @@ __device__ __forceinline__ int decompose_first(uint64_t x, uint32_t &state)
 // flipped: byte ^ 0x80 = byte - 128 mod 256), so that a digit is ONE signed bit-field extract at a (wave-uniform) bit offset and the
 // state is never shifted: decompose8x5_first returns the least significant digit (level 4), decompose8x5_at(state, 8 j) the digit of
 // level 3 - j.
-__device__ __forceinline__ int decompose8x5_first(uint64_t xr, uint32_t &state)
+__device__ __forceinline__ int decompose8x5_first_z(uint64_t z, uint32_t &state)      // z = rounded input + decompose_offset<8, 5>()
 {
-    const uint64_t z = xr + decompose_offset<8, 5>();
     state = (uint32_t)(z >> 32) ^ 0x80808080u;
     return (int)((uint32_t)z ^ 0x80000000u) >> 24;
+}
+__device__ __forceinline__ int decompose8x5_first(uint64_t xr, uint32_t &state)
+{
+    return decompose8x5_first_z(xr + decompose_offset<8, 5>(), state);
 }
 __device__ __forceinline__ int decompose8x5_at(uint32_t state, unsigned bit)
 {

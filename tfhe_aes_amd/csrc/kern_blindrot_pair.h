@@ -196,11 +196,15 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
                 static_assert(RND < (1ull << 31), "rounding constant must fit the low word");
                 fhe_u32x2 x0w, x1w, k0, k1;
                 x0w[0] = v0[0] ^ m0; x0w[1] = v0[1] ^ m0; x1w[0] = v1[0] ^ m1; x1w[1] = v1[1] ^ m1;
-                k0[0] = (uint32_t)RND - m0; k0[1] = 0; k1[0] = (uint32_t)RND - m1; k1[1] = 0;
+                // one 64-bit constant per coefficient carries the two's-complement "+1" (1 - ... = -m), the rounding 2^23 AND the
+                // decomposition's offset (fft_dev.h decompose_offset<8, 5>: 0x80 in each of the five digit bytes): no sum overflows a word
+                constexpr uint64_t OFF = decompose_offset<BASE_LOG, LEVELS>();
+                static_assert((uint32_t)OFF + RND < (1ull << 32), "offset + rounding constant must fit the low word");
+                k0[0] = (uint32_t)OFF + (uint32_t)RND - m0; k0[1] = (uint32_t)(OFF >> 32); k1[0] = (uint32_t)OFF + (uint32_t)RND - m1; k1[1] = (uint32_t)(OFF >> 32);
                 const uint64_t x0 = (__builtin_bit_cast(uint64_t, x0w) + lo[a]) + __builtin_bit_cast(uint64_t, k0);
                 const uint64_t x1 = (__builtin_bit_cast(uint64_t, x1w) + hi[a]) + __builtin_bit_cast(uint64_t, k1);
-                xr[a] = (double)decompose8x5_first(x0, st_lo[a]);
-                xi[a] = (double)decompose8x5_first(x1, st_hi[a]);
+                xr[a] = (double)decompose8x5_first_z(x0, st_lo[a]);
+                xi[a] = (double)decompose8x5_first_z(x1, st_hi[a]);
                 if ((a & (EP_ROT_CHUNK - 1)) == EP_ROT_CHUNK - 1) __builtin_amdgcn_sched_barrier(0);
             }
             wave_lds_sync();
