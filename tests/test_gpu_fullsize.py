@@ -172,3 +172,20 @@ def test_k2_launch_forms_agree_at_full_size(opt):
     E.synchronize()
     assert torch.equal(full[4096:8192], mid) and torch.equal(full[:256], lat)
     assert sha(full.cpu().numpy()) != sha(np.zeros_like(full.cpu().numpy()))
+
+
+def test_six_generation_launch_against_the_oracle_word_for_word(opt):
+    """A launch of the bench's kind -- 8,192 bits: six generations of the paired kernel on 256 CUs (1,024 six- and 512 four-ciphertext
+    units; the bench's 16,384-bit launch is eleven) -- compared with the CPU oracle on EVERY word, not only with the other kernel form
+    (test_k2_launch_forms_agree_at_full_size) or at two generations (test_gpu_stages.py: 2,100 bits).  8,192 x 669 external products on
+    the host: about 80 s on the GPU box's 16 cores (the oracle's batch entry point is OpenMP-parallel)."""
+    p, E = opt.params, opt.engine()
+    rng = np.random.default_rng(0xB16)
+    m = 8192
+    small = rng.integers(0, 1 << 64, (m, p.n + 1), dtype=np.uint64)
+    plan = E.k2_plan(m)
+    assert plan["form"] == 2 and (plan["units_main"], plan["units_tail"]) == (1024, 512)
+    out = np.zeros((m, p.big1), dtype=np.uint64)
+    E.cbs_pbs_batch(small, out, m)
+    want = opt.oracle.cbs_pbs(small)
+    assert out.shape == want.shape and np.array_equal(out, want)
