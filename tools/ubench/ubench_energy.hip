@@ -6,7 +6,7 @@
 //   idle      nothing (static power)
 //   fma       v_fma_f64 back to back (4 independent chains per lane)
 //   mfma i8   v_mfma_i32_16x16x64_i8 back to back on pseudo-random bytes (8 accumulators per wave)
-//   lds       ds_read_b128 from a conflict-free 16 KB window
+//   lds       ds_read_b128 from a conflict-free 16 KB window; round 5: LDS STORES (b128 random / constant data, 2 x b64, 4 x ds_write_addtid_b32)
 //   l1        buffer_load_dwordx4 of the same 8 KB per wave again and again (L1 hits)
 //   l2        every workgroup walks the same 2 MB (L2 hits after the first touch; the blind rotation's key rows)
 //   mall      every workgroup walks its own slice of 128 MB  (L2 misses, Infinity-Cache sized)
@@ -81,6 +81,50 @@ __global__ __launch_bounds__(512, 1) void k_lds(double *sink, int iters)
         asm volatile("" ::: "memory");
     }
     sink[blockIdx.x * 512 + threadIdx.x] = acc;
+}
+
+// LDS STORES (round 5): MODE 0 = ds_write_b128 of pseudo-random doubles (a fresh value per store: xorshift on the lane's registers),
+// 1 = ds_write_b128 of the same two doubles every time (what a stale-data proxy stores), 2 = two ds_write_b64, 3 = four
+// ds_write_addtid_b32 (no address VGPR; M0-relative, dword-interleaved across the lanes).  16 B per lane and step in every mode.
+template <int MODE>
+__global__ __launch_bounds__(512, 1) void k_lds_store(double *sink, int iters)
+{
+    __shared__ __attribute__((aligned(16))) double lds[8 * 1024];          // 64 KB
+    for (int i = threadIdx.x; i < 8 * 1024; i += 512) lds[i] = i;
+    __syncthreads();
+    unsigned long long a = 0x9E3779B97F4A7C15ull * (threadIdx.x + 1 + 512 * blockIdx.x), b = a ^ 0xD1B54A32D192ED03ull;
+    double2 *p = reinterpret_cast<double2 *>(lds) + threadIdx.x;           // 16 B per lane, consecutive: conflict-free
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (MODE != 1) { a ^= a << 13; a ^= a >> 7; a ^= a << 17; b += a; }    // new bits every store (integer work: priced by MODE 1's difference to a pure loop)
+            double2 v; v.x = __builtin_bit_cast(double, a); v.y = __builtin_bit_cast(double, b);
+            if (MODE <= 1) p[u * 512] = v;
+            else if (MODE == 2) {
+                reinterpret_cast<double *>(lds)[u * 1024 + threadIdx.x] = v.x;
+                reinterpret_cast<double *>(lds)[u * 1024 + 512 + threadIdx.x] = v.y;
+            } else {
+                const unsigned w0 = (unsigned)a, w1 = (unsigned)(a >> 32), w2 = (unsigned)b, w3 = (unsigned)(b >> 32);
+                const unsigned m0 = (unsigned)(u * 8192 + (threadIdx.x >> 6) * 1024);      // this wave's 1 KB: four planes of 256 B
+                asm volatile("s_mov_b32 m0, %4\n\tds_write_addtid_b32 %0 offset:0\n\tds_write_addtid_b32 %1 offset:256\n\t"
+                             "ds_write_addtid_b32 %2 offset:512\n\tds_write_addtid_b32 %3 offset:768"
+                             :: "v"(w0), "v"(w1), "v"(w2), "v"(w3), "s"(__builtin_amdgcn_readfirstlane(m0)) : "memory", "m0");
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+    __syncthreads();
+    sink[blockIdx.x * 512 + threadIdx.x] = lds[threadIdx.x] + __builtin_bit_cast(double, a);
+}
+// the integer work of k_lds_store<0> without its stores (what to subtract)
+__global__ __launch_bounds__(512, 1) void k_xorshift(double *sink, int iters)
+{
+    unsigned long long a = 0x9E3779B97F4A7C15ull * (threadIdx.x + 1 + 512 * blockIdx.x), b = a ^ 0xD1B54A32D192ED03ull;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a ^= a << 13; a ^= a >> 7; a ^= a << 17; b += a; asm volatile("" : "+v"(a), "+v"(b)); }
+    }
+    sink[blockIdx.x * 512 + threadIdx.x] = __builtin_bit_cast(double, a + b);
 }
 
 // walk `span` bytes (a multiple of 8 KB per wave step) starting at `base(blockIdx)`; 8 x 1 KB requests per wave per step
@@ -159,7 +203,7 @@ int main()
     const double idle_w = (energy_j() - e0) / 1.5;
     printf("%-8s %7.1f W\n", "idle", idle_w);
     auto report = [&](const char *name, Res r, double units, const char *unit) {
-        printf("%-8s %6.2f s  %8.1f J  %7.1f W   %8.2f pJ/%s above idle  (%.3g %s/s)\n", name, r.s, r.j, r.j / r.s, (r.j - idle_w * r.s) / units * 1e12, unit, units / r.s, unit);
+        printf("%-20s %6.2f s  %8.1f J  %7.1f W   %8.2f pJ/%s above idle  (%.3g %s/s)\n", name, r.s, r.j, r.j / r.s, (r.j - idle_w * r.s) / units * 1e12, unit, units / r.s, unit);
         fflush(stdout);
     };
     {
@@ -181,6 +225,15 @@ int main()
         double n = 0; const int it = 100000;
         Res r = timed([&] { hipLaunchKernelGGL(k_lds, dim3(G), dim3(512), 0, 0, sink, it); n += (double)G * 512 * it * 8 * 16; });
         report("lds", r, n, "B");
+    }
+    {
+        const int it = 50000;
+        const double per = (double)G * 512 * it * 8 * 16;
+        { double n = 0; Res r = timed([&] { hipLaunchKernelGGL(k_xorshift, dim3(G), dim3(512), 0, 0, sink, it); n += per; }); report("xorshift (no store)", r, n, "B-equivalent"); }
+        { double n = 0; Res r = timed([&] { hipLaunchKernelGGL(k_lds_store<0>, dim3(G), dim3(512), 0, 0, sink, it); n += per; }); report("lds st b128 rnd", r, n, "B"); }
+        { double n = 0; Res r = timed([&] { hipLaunchKernelGGL(k_lds_store<1>, dim3(G), dim3(512), 0, 0, sink, it); n += per; }); report("lds st b128 const", r, n, "B"); }
+        { double n = 0; Res r = timed([&] { hipLaunchKernelGGL(k_lds_store<2>, dim3(G), dim3(512), 0, 0, sink, it); n += per; }); report("lds st 2xb64 rnd", r, n, "B"); }
+        { double n = 0; Res r = timed([&] { hipLaunchKernelGGL(k_lds_store<3>, dim3(G), dim3(512), 0, 0, sink, it); n += per; }); report("lds st 4xaddtid", r, n, "B"); }
     }
     const int steps = 20000;
     const double per_launch = (double)G * 512 * steps * 8 * 16;
