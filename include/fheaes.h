@@ -203,7 +203,7 @@ int fheaes_k2_launch_plan(uint64_t m, uint32_t cu_count, uint32_t k, int *form, 
                           uint64_t *units_tail, uint32_t *r_tail);
 /* The same for a CONTEXT: the form and the kernel this context really launches for a batch of `m` bits on its device, after the
  * occupancy fallbacks (the paired kernel needs 159,488 B of LDS per workgroup: where the runtime cannot place one on a CU every batch
- * takes form 1; the 16-form's LDS-home variant needs two workgroups of 81,920 B per CU, else its parked variant runs).  `kernel`
+ * takes form 1 -- and, because its parking slab is indexed by the physical CU, also where the runtime would place MORE than one; the 16-form's LDS-home variant needs two workgroups of 81,920 B per CU, else its parked variant runs).  `kernel`
  * (may be NULL) receives the kernel's name, e.g. "blind_rotate_pair_kernel<5,5,8,3,2>".  Measurements must be labelled from this call. */
 int fheaes_k2_context_plan(fheaes_ctx *ctx, uint64_t m, int *form, uint64_t *units_main, uint32_t *r_main, uint64_t *units_tail,
                            uint32_t *r_tail, char *kernel, size_t kernel_cap);

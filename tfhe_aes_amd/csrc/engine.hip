@@ -493,7 +493,9 @@ bool k2_pair_allowed(fheaes_ctx *c)
     if (c->k2_pair_ok < 0) {
         int per_cu = 0;
         const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blind_rotate_pair_kernel<5, 5, 8, 3, 2>, BRP_THREADS, 0);
-        c->k2_pair_ok = (oe == hipSuccess && per_cu >= 1) ? 1 : 0;
+        // ... and, with the parking slab indexed by the physical CU (BRP_PARK_BY_CU), where it places EXACTLY one: two co-resident
+        // workgroups of one CU would share a slab slot
+        c->k2_pair_ok = (oe == hipSuccess && (BRP_PARK_BY_CU ? per_cu == 1 : per_cu >= 1)) ? 1 : 0;
         (void)hipGetLastError();
     }
     return c->k2_pair_ok == 1;
@@ -554,7 +556,7 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         const K2Plan pl = k2_plan(m, c->cu_count, c->k1, true);
         const unsigned gridp = (unsigned)(pl.units_main + pl.units_tail);
         a.units_main = (uint32_t)pl.units_main;
-        const size_t park_bytes = (size_t)gridp * 2 * BRP_PARK_WORDS_PER_HALF * 8;
+        const size_t park_bytes = (size_t)(BRP_PARK_BY_CU ? BRP_PARK_SLOTS : gridp) * 2 * BRP_PARK_WORDS_PER_HALF * 8;
         if (park_bytes > 0x7FFFFFFFull) return c->fail(FHEAES_ERR_INVALID, "internal: parking slab of %zu bytes exceeds one raw buffer", park_bytes);
         TRY(ensure(c, c->ws_park, park_bytes));
         a.park = (uint64_t *)c->ws_park.p; a.park_bytes = park_bytes;
@@ -937,7 +939,7 @@ int fheaes_reserve(fheaes_ctx *c, uint64_t max_bits)
         // the blind rotation's parking slab for the largest launch this reservation covers (64 KB per workgroup)
         const K2Plan pl = k2_plan(bits, c->cu_count, c->k1, k2_pair_allowed(c));
         if (pl.form == 1) TRY(ensure(c, c->ws_park, (size_t)(pl.units_main + pl.units_tail) * BR16_PARK_WORDS_PER_WG * 8));
-        if (pl.form == 2) TRY(ensure(c, c->ws_park, (size_t)(pl.units_main + pl.units_tail) * 2 * BRP_PARK_WORDS_PER_HALF * 8));
+        if (pl.form == 2) TRY(ensure(c, c->ws_park, (size_t)(BRP_PARK_BY_CU ? BRP_PARK_SLOTS : pl.units_main + pl.units_tail) * 2 * BRP_PARK_WORDS_PER_HALF * 8));
     }
     return FHEAES_OK;
 }

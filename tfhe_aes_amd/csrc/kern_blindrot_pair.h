@@ -41,6 +41,14 @@
 #define BRP_W1_LATE 2           /* 1: second half of the table column requested at the start of the twiddle pass; 2: in two requests of four entries, each
                                 into registers the first half has just left (no spill with hi[] resident: 249 VGPRs) */
 #endif
+#ifndef BRP_PARK_BY_CU
+#define BRP_PARK_BY_CU 1     /* 1 (round 5: 203.9 -> 199.2 ms per 16,384-bit launch, -2.4 % joules, same words): the parking slab is indexed by the PHYSICAL compute unit the workgroup runs on (HW_REG_XCC_ID, HW_REG_HW_ID: XCC, SE, SH, CU --
+                                this kernel fits one workgroup per CU, so the tuple is a collision-free slot: tools/ubench/ubench_cuid.hip), 1,024 slots of
+                                64 KB = 64 MB that every generation reuses, instead of 64 KB per workgroup of the launch (180 MB per 16,384 bits): the 16 MB a
+                                launch really touches stay in the L2s / the Infinity Cache.  engine.hip uses this kernel only where the occupancy query says
+                                EXACTLY one workgroup per CU (k2_pair_allowed); 0 = one slab per workgroup */
+#endif
+#define BRP_PARK_SLOTS 1024
 #ifndef BRP_MAC_PRIO
 #define BRP_MAC_PRIO 1       /* wave priority during the multiply-accumulate (0 / 1 / 3: 214.2 / 211.8 / 212.0 ms per 16,384-bit launch) */
 #endif
@@ -125,7 +133,15 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
         }
     }
     const __amdgpu_buffer_rsrc_t park_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.park, 0, (int)A.park_bytes, 0x00020000);
+#if BRP_PARK_BY_CU
+    unsigned hw_xcc, hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw_xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    const unsigned park_slot = ((hw_xcc & 7u) << 7) | ((hw_id >> 8) & 0x7Fu);       // XCC[2:0] | SE_ID[2:0] SH_ID CU_ID[3:0] (HW_ID bits 14..8)
+    const unsigned park_wg = (park_slot * 2u + (unsigned)hh) * (unsigned)(BRP_PARK_WORDS_PER_HALF * 8);      // wave-uniform
+#else
     const unsigned park_wg = (unit_index * 2u + (unsigned)hh) * (unsigned)(BRP_PARK_WORDS_PER_HALF * 8);       // wave-uniform
+#endif
 #define BRP_PARK_SLOT(a) ((unsigned)(a) * (EP_THREADS * 16))
     __syncthreads();   // tables visible
 

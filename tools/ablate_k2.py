@@ -27,7 +27,8 @@ VARIANTS = {
     "nobar_skew80": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=80"], "nobar_skew160": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=160"],
  "nopeel": ["-DBRP_ABL_NOPEEL"], "noload": ["-DBR16_ABL_NOLOAD"], "nopark": ["-DBR16_ABL_NOPARK"],
     "nostores_noload": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NODSTORE", "-DBR16_ABL_NOLOAD"],
-    "all6": ["-DK2_PAIR_TAIL4=0"], "fewcmul": ["-DBRP_ABL_FEWCMUL"],
+    "all6": ["-DK2_PAIR_TAIL4=0"], "parkcu": ["-DBRP_PARK_BY_CU=1"], "parkcu_ld0": ["-DBRP_PARK_BY_CU=1", "-DBR16_PARK_AUX_LD=0"],
+    "parkcu_ld0_st16": ["-DBRP_PARK_BY_CU=1", "-DBR16_PARK_AUX_LD=0", "-DBR16_PARK_AUX_ST=16"], "fewcmul": ["-DBRP_ABL_FEWCMUL"],
     # ---- round 4: parking ----
     "nohome": ["-DBR16_W3_LDS_HOME=0"],                                   # wavefront 3 parks like the others (idle lanes still skip)
     "r3park": ["-DBR16_W3_LDS_HOME=0", "-DBR16_PARK_OWNERS_ONLY=0"],      # round-3 behaviour: every lane parks
