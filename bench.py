@@ -106,6 +106,23 @@ def cpu_baseline(p, keys, client, seconds_hint: float = 20.0):
     }
 
 
+def u128_bytes(x: int):
+    return [(x >> (8 * (15 - b))) & 0xFF for b in range(16)]
+
+
+def wrong_blocks(client, ct, want) -> list:
+    """client.rs:147-175 decrypts and asserts EVERY block (`assert_eq` at :171): indices of the blocks of `ct`
+    ([n][16][8][kN+1] device tensor) whose decryption differs from want[i] (128-bit integers)"""
+    got = client.decrypt_bytes(ct.cpu().numpy().view(np.uint64))            # [n][16]
+    return [i for i, w in enumerate(want) if [int(v) for v in got[i]] != u128_bytes(w)]
+
+
+def words_sha(t) -> str:
+    import hashlib
+
+    return hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,17 +317,18 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(p, keys, client)
 
-    # ---- verify a sample: decrypt == AES applied (warmup+steps) times to the counter -----------------
-    verified = None
+    # ---- verify EVERY block (the reference asserts every block, client.rs:171): decrypt == AES applied (warmup+steps) times ----
+    verified, wrong = None, {}
     if not args.no_verify:
-        verified = True
-        for idx in sorted({0, n_blocks // 2, n_blocks - 1}):
-            got = client.decrypt_u128(state[idx].cpu().numpy().view(np.uint64))
-            want = counters[idx]
-            for _ in range(1 if args.ctr_add else args.warmup + args.steps):
-                want = aes128_decrypt_block(KEY, want) if args.decrypt else aes128_encrypt_block(KEY, want)
-            if got != want:
-                verified = False
+        want = list(counters)
+        for _ in range(1 if args.ctr_add else args.warmup + args.steps):
+            want = [aes128_decrypt_block(KEY, w) if args.decrypt else aes128_encrypt_block(KEY, w) for w in want]
+        if os.environ.get("FHEAES_BENCH_SABOTAGE_VERIFY") == "1":       # tests/test_gpu_bench_dist.py: the failure path must be reachable
+            want[0] ^= 1
+        bad = wrong_blocks(client, state, want)
+        if bad:
+            wrong["headline_rank%d" % rank] = bad
+        verified = not bad
         if world > 1:
             v = torch.tensor([1 if verified else 0], device=dev)
             dist.all_reduce(v, op=dist.ReduceOp.MIN)
@@ -327,9 +345,10 @@ def main():
         eng.aes_encrypt(rk, st2, n_blocks)
         eng.synchronize()
         dt = time.perf_counter() - t0
-        ok = all(client.decrypt_u128(st2[i].cpu().numpy().view(np.uint64)) == aes128_encrypt_block(KEY, (IV + lo + i) & ((1 << 128) - 1))
-                 for i in sorted({0, n_blocks // 2, n_blocks - 1}))
-        ctr_iter = {"blocks_per_s": n_blocks / dt, "ms": 1000.0 * dt, "verified_vs_aes": bool(ok),
+        bad = wrong_blocks(client, st2, [aes128_encrypt_block(KEY, (IV + lo + i) & ((1 << 128) - 1)) for i in range(n_blocks)])
+        if bad:
+            wrong["ctr_iteration"] = bad
+        ctr_iter = {"blocks_per_s": n_blocks / dt, "ms": 1000.0 * dt, "verified_vs_aes": not bad, "blocks_checked": n_blocks,
                     "note": "one step of %d blocks: Server::add_scalar(encrypted_iv, i) on the GPU (143 bit-CBS per block, 16-step carry chain), "
                             "then Server::aes_encrypt; the timed `value` uses client-side pre-incremented counters" % n_blocks}
         del st2
@@ -340,6 +359,7 @@ def main():
         st4 = state[:32].clone()
         eng.aes_decrypt(rk, st4, 32)                      # warm-up (workspace growth for the 4-LUT packing)
         eng.synchronize()                                 # the engine has its own stream: finish before torch overwrites st4
+        sha_warm = words_sha(st4)
         st4.copy_(state[:32])
         torch.cuda.synchronize()
         eng.profile_enable(True)
@@ -351,18 +371,22 @@ def main():
         dt = time.perf_counter() - t0
         pr4 = eng.profile_read()
         eng.profile_enable(False)
-        ok = True
-        for i in (0, 15, 31):
-            want = counters[i]
-            for _ in range(args.warmup + args.steps - 1):
-                want = aes128_encrypt_block(KEY, want)
-            ok = ok and client.decrypt_u128(st4[i].cpu().numpy().view(np.uint64)) == want
+        want4 = list(counters[:32])
+        for _ in range(args.warmup + args.steps - 1):
+            want4 = [aes128_encrypt_block(KEY, w) for w in want4]
+        bad = wrong_blocks(client, st4, want4)
+        if bad:
+            wrong["configs4_decrypt"] = bad
+        sha_timed = words_sha(st4)
+        if sha_timed != sha_warm:                         # the same input twice: the engine is deterministic, so other words = a race
+            wrong["configs4_decrypt_not_deterministic"] = [sha_warm[:16], sha_timed[:16]]
         b4 = pr4["blind_rotate"]
         l4 = max(1, b4["launches"])
         k2_ms = b4["ms"] / l4
         f4 = (b4["units"] / l4) * p.n * ext_product_flops(p) / (k2_ms * 1e-3) / 1e12 if k2_ms > 0 else 0.0
         kp4 = eng.k2_plan(int(b4["units"] // l4))
-        dec32 = {"blocks_per_s": 32 / dt, "ms": 1000.0 * dt, "verified_vs_aes": bool(ok), "k2_launches": l4, "k2_bits_per_launch": b4["units"] / l4,
+        dec32 = {"blocks_per_s": 32 / dt, "ms": 1000.0 * dt, "verified_vs_aes": not bad, "blocks_checked": 32,
+                 "same_words_as_warmup_run": sha_timed == sha_warm, "words_sha256": sha_timed[:16], "k2_launches": l4, "k2_bits_per_launch": b4["units"] / l4,
                  "k2_ms_per_launch": k2_ms, "k2_form": kp4["form"], "k2_kernel": kp4["kernel"], "k2_frac_of_f64_valu_peak": f4 / F64_VALU_PEAK_TFLOPS,
                  "note": "BASELINE configs[4] per-GPU shard (256 blocks / 8 GPUs): Server::aes_decrypt on 32 resident blocks, 2,432 bit-CBS per block "
                          "(inverse S-Box + 4-LUT inverse MixColumns packing, server.rs:67-105); one step, every launch is 4,096 bits"}
@@ -398,13 +422,13 @@ def main():
         for t_ in ths:
             t_.join()
         dt = time.perf_counter() - t0
-        ok = True
-        for hidx, bidx in ((0, 0), (1, half - 1)):
-            want = counters[hidx * half + bidx]
-            for _ in range(args.warmup + args.steps + 1):
-                want = aes128_encrypt_block(KEY, want)
-            ok = ok and client.decrypt_u128(halves[hidx][bidx].cpu().numpy().view(np.uint64)) == want
-        two_ctx = {"blocks_per_s": 2 * half / dt, "ms": 1000.0 * dt, "verified_vs_aes": bool(ok), "blocks_per_context": half,
+        want2 = list(counters[:2 * half])
+        for _ in range(args.warmup + args.steps + 1):
+            want2 = [aes128_encrypt_block(KEY, w) for w in want2]
+        bad = [hidx * half + i for hidx in range(2) for i in wrong_blocks(client, halves[hidx], want2[hidx * half:(hidx + 1) * half])]
+        if bad:
+            wrong["two_contexts"] = bad
+        two_ctx = {"blocks_per_s": 2 * half / dt, "ms": 1000.0 * dt, "verified_vs_aes": not bad, "blocks_checked": 2 * half, "blocks_per_context": half,
                    "clone": {"path": ci["path"], "bytes": ci["bytes"], "seconds": round(ci["seconds"], 4)},
                    "note": "two fheaes contexts on this one GPU (fheaes_clone_keys: one upload, device-to-device copy of the converted key images), "
                            "%d blocks of Server::aes_encrypt each from two host threads, concurrently: the in-process shape of the reference's rayon "
@@ -425,6 +449,13 @@ def main():
             eng.many_sbox(xb, 16, False, ob)
         eng.synchronize()
         one_block_ms = 1000.0 * (time.perf_counter() - t0) / 3
+        if not args.no_verify:
+            from tfhe_aes_amd.aes_clear import SBOX, mul2, mul3
+            xin = [int(v) for v in client.decrypt_bytes(xb.cpu().numpy().view(np.uint64))]                 # the 16 input bytes
+            got = client.decrypt_bytes(ob.cpu().numpy().view(np.uint64))                                   # [16][3]
+            bad = [i for i in range(16) if [int(v) for v in got[i]] != [SBOX[xin[i]], mul2(SBOX[xin[i]]), mul3(SBOX[xin[i]])]]
+            if bad:
+                wrong["config1_many_sbox_bytes"] = bad
 
     if rank == 0:
         total_blocks = args.blocks * world
@@ -470,7 +501,11 @@ def main():
             },
             "ms_per_sbox": ms_per_step / (args.blocks * (304.0 if args.decrypt else 160.0)),
             "verified_vs_aes": verified,
-            "config1_one_block_round": {"many_sbox_16_bytes_ms": one_block_ms, "ms_per_sbox": None if one_block_ms is None else one_block_ms / 16.0,
+            # every block of the headline and of every extra step is decrypted and compared (the reference asserts every block,
+            # client.rs:171); anything wrong is listed by step -> block indices and the process exits 1 after printing this line
+            "all_verified": None if args.no_verify else bool(verified) and not wrong, "wrong_blocks": wrong,
+            "blocks_checked": None if args.no_verify else n_blocks,
+            "config1_one_block_round": {"many_sbox_16_bytes_ms": one_block_ms, "verified_vs_aes": None if args.no_verify else "config1_many_sbox_bytes" not in wrong, "ms_per_sbox": None if one_block_ms is None else one_block_ms / 16.0,
                                         "note": "BASELINE configs[1]: 16 S-Box WoPBS (128 bit-CBS) in one call: latency of the 669-step rotation chain"},
             "ctr_iteration_with_add_scalar": ctr_iter,
             "configs4_decrypt_32_blocks": dec32,
@@ -526,6 +561,10 @@ def main():
     if world > 1 or rccl1 is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not args.no_verify and (wrong or not verified):
+        # a wrong plaintext is a failed run, whatever the throughput: the line above says where, the exit code says so to a driver
+        print("bench.py: verification FAILED: %s" % (json.dumps(wrong) if wrong else "another rank's blocks"), file=sys.stderr, flush=True)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

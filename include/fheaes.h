@@ -202,11 +202,18 @@ int fheaes_read_bsk_fourier(fheaes_ctx *ctx, uint32_t i, double *out);
 int fheaes_k2_launch_plan(uint64_t m, uint32_t cu_count, uint32_t k, int *form, uint64_t *units_main, uint32_t *r_main,
                           uint64_t *units_tail, uint32_t *r_tail);
 /* The same for a CONTEXT: the form and the kernel this context really launches for a batch of `m` bits on its device, after the
- * occupancy fallbacks (the paired kernel needs 159,488 B of LDS per workgroup: where the runtime cannot place one on a CU every batch
- * takes form 1 -- and, because its parking slab is indexed by the physical CU, also where the runtime would place MORE than one; the 16-form's LDS-home variant needs two workgroups of 81,920 B per CU, else its parked variant runs).  `kernel`
+ * occupancy fallbacks (the paired kernel needs 159,504 B of LDS per workgroup: where the runtime cannot place one on a CU every batch
+ * takes form 1; the 16-form's LDS-home variant needs two workgroups of 81,920 B per CU, else its parked variant runs).  `kernel`
  * (may be NULL) receives the kernel's name, e.g. "blind_rotate_pair_kernel<5,5,8,3,2>".  Measurements must be labelled from this call. */
 int fheaes_k2_context_plan(fheaes_ctx *ctx, uint64_t m, int *form, uint64_t *units_main, uint32_t *r_main, uint64_t *units_tail,
                            uint32_t *r_tail, char *kernel, size_t kernel_cap);
+/* Where the paired blind-rotation kernel parks the half of its accumulators that does not fit a CU's registers and LDS: `claimed` = 1
+ * (default): 64 KB slots of a shared pool, 128 per XCC, claimed with one compare-and-swap when a workgroup starts and released when it
+ * ends, so that the slots the resident workgroups use stay in the caches; 0: one private slot per workgroup of the launch (64 KB x
+ * the grid).  Same words either way (tests/test_gpu_fullsize.py).  The name `fheaes_k2_context_plan` reports carries the setting
+ * (" parking=claimed" / " parking=private").  Ownership of a slot is recorded in memory and never inferred from the compute unit a
+ * workgroup runs on: a queue preempted mid-kernel resumes its workgroups on other compute units (round 5's defect). */
+int fheaes_k2_set_parking(fheaes_ctx *ctx, int claimed);
 const char *fheaes_version(void);
 
 #ifdef __cplusplus

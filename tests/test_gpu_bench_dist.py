@@ -129,6 +129,37 @@ def test_bench_single_rank_line_has_the_extra_verified_steps():
         assert abs(r["model_frac"] - r["frac_of_profiled_launch"]) <= 0.03 * r["frac_of_profiled_launch"]
 
 
+def test_bench_driver_shape_at_param_opt_verifies_every_block():
+    """the driver's command at reduced cost (PARAM_OPT, 32 blocks, 6 + 2 steps, no CPU baseline): every block of the headline and of
+    every extra step is decrypted and compared, the line says so (`all_verified`, `wrong_blocks`), and a wrong block is a non-zero exit"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--params", "opt", "--blocks", "32", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                         cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert line["all_verified"] is True and line["wrong_blocks"] == {} and line["blocks_checked"] == 32
+    assert line["ctr_iteration_with_add_scalar"]["blocks_checked"] == 32 and line["configs4_decrypt_32_blocks"]["blocks_checked"] == 32
+    assert line["configs4_decrypt_32_blocks"]["same_words_as_warmup_run"] is True
+    assert line["two_contexts_64_blocks_each"]["blocks_checked"] == 32 and line["config1_one_block_round"]["verified_vs_aes"] is True
+    assert line["roofline"]["kernel"].startswith("blind_rotate_pair_kernel") and "parking=claimed" in line["roofline"]["kernel"]
+
+
+def test_bench_exit_code_follows_verification(tmp_path):
+    """a bench that cannot fail is no check: with the expected plaintexts made wrong on purpose (FHEAES_BENCH_SABOTAGE_VERIFY=1 flips one
+    bit of what block 0 is compared with) the line still prints, says all_verified false with the block listed, and the exit code is 1"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    env["FHEAES_BENCH_SABOTAGE_VERIFY"] = "1"
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--params", "toy", "--blocks", "4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                          "--no-ctr-iteration"], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 1, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][0])
+    assert line["all_verified"] is False and line["verified_vs_aes"] is False and line["wrong_blocks"] == {"headline_rank0": [0]}
+
+
 def test_bench_refuses_world_size_mismatch():
     """--gpus must equal WORLD_SIZE: a silent single-rank run of a "2 GPU" bench would be an invalid number"""
     res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--params", "toy", "--blocks", "1"], cwd=str(ROOT),

@@ -62,6 +62,7 @@ SIGNATURES = {
                                        _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint32)]),
     "fheaes_k2_context_plan": (_c.c_int, [_ctx, _c.c_uint64, _c.POINTER(_c.c_int), _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint32),
                                         _c.POINTER(_c.c_uint64), _c.POINTER(_c.c_uint32), _c.c_char_p, _c.c_size_t]),
+    "fheaes_k2_set_parking": (_c.c_int, [_ctx, _c.c_int]),
     "fheaes_version": (_c.c_char_p, []),
 }
 
@@ -270,6 +271,10 @@ class Engine:
         self._check(self._lib.fheaes_k2_context_plan(self._h, bits, _c.byref(form), _c.byref(um), _c.byref(rm), _c.byref(ut), _c.byref(rt), name, len(name)))
         return {"form": form.value, "kernel": name.value.decode(), "units_main": um.value, "r_main": rm.value,
                 "units_tail": ut.value, "r_tail": rt.value}
+
+    def k2_set_parking(self, claimed: bool):
+        """paired blind-rotation kernel: parking slots claimed from a shared pool (default) or one private slot per workgroup"""
+        self._check(self._lib.fheaes_k2_set_parking(self._h, 1 if claimed else 0))
 
     def read_bsk_fourier(self, i: int) -> np.ndarray:
         p = self.params

@@ -212,7 +212,8 @@ struct fheaes_ctx {
     // layers count how many nominal-noise ciphertexts (fresh WoPBS outputs, round keys, client encryptions) they sum into one
     uint32_t noise_level_seen = 0;
     int k2_home = -1;                    // blind rotation: 1 = the LDS-home form runs two workgroups per CU here (queried once), 0 = parked form
-    int k2_pair_ok = -1;                 // 1 = the paired kernel (159,488 B of LDS per workgroup) can be resident on a CU here (queried once)
+    int k2_pair_ok = -1;                 // 1 = the paired kernel (159,504 B of LDS per workgroup) can be resident on a CU here (queried once)
+    int k2_park_claim = 1;               // paired kernel's parking slots: 1 = claimed from a shared pool (kern_blindrot_pair.h), 0 = one private slot per workgroup
     // keys
     int8_t *ksk_frag = nullptr, *pfpksk_frag = nullptr;      // balanced key bytes in MFMA B-fragment order
     uint32_t ks_ksteps = 0, ks_coltiles = 0, pf_ksteps = 0, pf_coltiles = 0;
@@ -224,7 +225,7 @@ struct fheaes_ctx {
     uint64_t *lutset_d[LUTSET_COUNT] = {};
     int lutset_n[LUTSET_COUNT] = {};
     // workspace
-    DevBuf ws_small, ws_pbs, ws_ggsw, ws_ggswf, ws_vp, ws_tmp_a, ws_tmp_b, ws_luts, ws_misc, ws_digits, ws_park, ws_tree;
+    DevBuf ws_small, ws_pbs, ws_ggsw, ws_ggswf, ws_vp, ws_tmp_a, ws_tmp_b, ws_luts, ws_misc, ws_digits, ws_park, ws_park_owner, ws_tree;
     DevBuf stage[4];                     // host-memspace calls stage their arguments here (grow-only, reused)
     // pinned host staging for the counter bytes of add_scalar; `pin_ev` marks the last copy out of it
     uint8_t *pin = nullptr;
@@ -493,9 +494,7 @@ bool k2_pair_allowed(fheaes_ctx *c)
     if (c->k2_pair_ok < 0) {
         int per_cu = 0;
         const hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, blind_rotate_pair_kernel<5, 5, 8, 3, 2>, BRP_THREADS, 0);
-        // ... and, with the parking slab indexed by the physical CU (BRP_PARK_BY_CU), where it places EXACTLY one: two co-resident
-        // workgroups of one CU would share a slab slot
-        c->k2_pair_ok = (oe == hipSuccess && (BRP_PARK_BY_CU ? per_cu == 1 : per_cu >= 1)) ? 1 : 0;
+        c->k2_pair_ok = (oe == hipSuccess && per_cu >= 1) ? 1 : 0;
         (void)hipGetLastError();
     }
     return c->k2_pair_ok == 1;
@@ -514,13 +513,20 @@ bool k2_home_allowed(fheaes_ctx *c)
     return c->k2_home == 1;
 }
 
+// bytes of the paired kernel's parking slab for a launch of `grid` workgroups: claimed slots = the shared pool + one private overflow slot
+// per workgroup behind it (never touched unless a pool is exhausted), private slots = one per workgroup
+size_t k2_pair_park_bytes(const fheaes_ctx *c, uint64_t grid)
+{
+    return (size_t)((c->k2_park_claim ? BRP_PARK_SLOTS : 0) + grid) * 2 * BRP_PARK_WORDS_PER_HALF * 8;
+}
+
 // the kernel a blind-rotation batch of m bits really takes on this context (form of K2Plan after the occupancy fallbacks) and its name
 K2Plan k2_context_plan(fheaes_ctx *c, uint64_t m, const char **kernel)
 {
     const K2Plan pl = k2_plan(m, c->cu_count, c->k1, k2_pair_allowed(c));
     if (kernel) {
         if (pl.form == 0) *kernel = c->k1 == 5 ? "blind_rotate_latency_kernel<5,5,8>" : "blind_rotate_latency_kernel<2,5,8>";
-        else if (pl.form == 2) *kernel = "blind_rotate_pair_kernel<5,5,8,3,2>";
+        else if (pl.form == 2) *kernel = c->k2_park_claim ? "blind_rotate_pair_kernel<5,5,8,3,2> parking=claimed" : "blind_rotate_pair_kernel<5,5,8,3,2> parking=private";
         else if (c->k1 != 5) *kernel = "blind_rotate16_kernel<2,5,8,8,0,false>";
         else *kernel = k2_home_allowed(c) ? "blind_rotate16_kernel<5,5,8,3,2,true>" : "blind_rotate16_kernel<5,5,8,3,2,false>";
     }
@@ -556,10 +562,17 @@ int launch_cbs_pbs(fheaes_ctx *c, const uint64_t *lwe_small, uint64_t m, uint32_
         const K2Plan pl = k2_plan(m, c->cu_count, c->k1, true);
         const unsigned gridp = (unsigned)(pl.units_main + pl.units_tail);
         a.units_main = (uint32_t)pl.units_main;
-        const size_t park_bytes = (size_t)(BRP_PARK_BY_CU ? BRP_PARK_SLOTS : gridp) * 2 * BRP_PARK_WORDS_PER_HALF * 8;
+        const size_t park_bytes = k2_pair_park_bytes(c, gridp);
         if (park_bytes > 0x7FFFFFFFull) return c->fail(FHEAES_ERR_INVALID, "internal: parking slab of %zu bytes exceeds one raw buffer", park_bytes);
         TRY(ensure(c, c->ws_park, park_bytes));
         a.park = (uint64_t *)c->ws_park.p; a.park_bytes = park_bytes;
+        if (c->k2_park_claim) {
+            // owner words of the shared slots: all free when a launch starts (every workgroup gives its slot back before it ends; the
+            // memset makes that hold even after a launch that was aborted)
+            TRY(ensure(c, c->ws_park_owner, BRP_PARK_SLOTS * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemsetAsync(c->ws_park_owner.p, 0, BRP_PARK_SLOTS * sizeof(uint32_t), c->stream));
+            a.park_owner = (uint32_t *)c->ws_park_owner.p;
+        }
 #ifdef EP_STAMPS
         static const char *namesP[EP_NPH] = {"stage+rotate+decomp_first", "decomp_next", "fwd head", "pre-level barrier", "fwd tail (transpose+dft16)",
                                              "digit stores+late loads", "exchange barrier", "MAC", "products exchange", "inverse fft", "convert+add", "loop head"};
@@ -800,6 +813,15 @@ int fheaes_k2_context_plan(fheaes_ctx *ctx, uint64_t m, int *form, uint64_t *uni
     if (kernel && kernel_cap) { std::strncpy(kernel, name, kernel_cap - 1); kernel[kernel_cap - 1] = 0; }
     return FHEAES_OK;
 }
+int fheaes_k2_set_parking(fheaes_ctx *ctx, int claimed)
+{
+    if (!ctx) return FHEAES_ERR_INVALID;
+    CtxLock lock__(ctx);
+    if (claimed != 0 && claimed != 1) return ctx->fail(FHEAES_ERR_INVALID, "k2_set_parking: 1 = claimed slots, 0 = one private slot per workgroup (got %d)", claimed);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->k2_park_claim = claimed;
+    return FHEAES_OK;
+}
 const char *fheaes_version(void) { return FHEAES_VERSION_STR; }
 
 const char *fheaes_last_error(const fheaes_ctx *ctx)
@@ -886,7 +908,7 @@ void fheaes_destroy(fheaes_ctx *c)
     for (auto ev : c->free_events) (void)hipEventDestroy(ev);
     void *ptrs[] = {c->ksk_frag, c->pfpksk_frag, c->bskf, c->tw_d, c->ws_digits.p,
                     c->ws_small.p, c->ws_pbs.p, c->ws_ggsw.p, c->ws_ggswf.p, c->ws_vp.p, c->ws_tmp_a.p, c->ws_tmp_b.p, c->ws_luts.p, c->ws_misc.p,
-                    c->ws_park.p, c->ws_tree.p};
+                    c->ws_park.p, c->ws_park_owner.p, c->ws_tree.p};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (auto &b : c->stage) if (b.p) (void)hipFree(b.p);
     if (c->pin) (void)hipHostFree(c->pin);
@@ -939,7 +961,10 @@ int fheaes_reserve(fheaes_ctx *c, uint64_t max_bits)
         // the blind rotation's parking slab for the largest launch this reservation covers (64 KB per workgroup)
         const K2Plan pl = k2_plan(bits, c->cu_count, c->k1, k2_pair_allowed(c));
         if (pl.form == 1) TRY(ensure(c, c->ws_park, (size_t)(pl.units_main + pl.units_tail) * BR16_PARK_WORDS_PER_WG * 8));
-        if (pl.form == 2) TRY(ensure(c, c->ws_park, (size_t)(BRP_PARK_BY_CU ? BRP_PARK_SLOTS : pl.units_main + pl.units_tail) * 2 * BRP_PARK_WORDS_PER_HALF * 8));
+        if (pl.form == 2) {
+            TRY(ensure(c, c->ws_park, k2_pair_park_bytes(c, pl.units_main + pl.units_tail)));
+            TRY(ensure(c, c->ws_park_owner, BRP_PARK_SLOTS * sizeof(uint32_t)));
+        }
     }
     return FHEAES_OK;
 }

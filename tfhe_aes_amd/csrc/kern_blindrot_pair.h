@@ -41,14 +41,25 @@
 #define BRP_W1_LATE 2           /* 1: second half of the table column requested at the start of the twiddle pass; 2: in two requests of four entries, each
                                 into registers the first half has just left (no spill with hi[] resident: 249 VGPRs) */
 #endif
-#ifndef BRP_PARK_BY_CU
-#define BRP_PARK_BY_CU 1     /* 1 (round 5: 203.9 -> 199.2 ms per 16,384-bit launch, -2.4 % joules, same words): the parking slab is indexed by the PHYSICAL compute unit the workgroup runs on (HW_REG_XCC_ID, HW_REG_HW_ID: XCC, SE, SH, CU --
-                                this kernel fits one workgroup per CU, so the tuple is a collision-free slot: tools/ubench/ubench_cuid.hip), 1,024 slots of
-                                64 KB = 64 MB that every generation reuses, instead of 64 KB per workgroup of the launch (180 MB per 16,384 bits): the 16 MB a
-                                launch really touches stay in the L2s / the Infinity Cache.  engine.hip uses this kernel only where the occupancy query says
-                                EXACTLY one workgroup per CU (k2_pair_allowed); 0 = one slab per workgroup */
-#endif
+// Parking slots (round 6).  The parked half of the accumulator lives in a slab of 64 KB slots.  A workgroup's slot is either
+//   * CLAIMED (ExtProdArgs::park_owner != null, the default): the first BRP_PARK_SLOTS = 8 x 128 slots are shared by all generations of
+//     all launches -- 128 per XCC (HW_REG_XCC_ID: only that XCC's L2 ever caches a slot's lines, so a slot never needs a cross-XCC
+//     hand-over), taken with one compare-and-swap on an owner word at the workgroup's start (the probe starts at the slot its
+//     predecessor on this compute unit has just released: HW_REG_HW_ID[14:8] is a HINT, nothing depends on its value) and given back
+//     after the workgroup's last parking access has been acknowledged.  The 16 MB the 256 resident workgroups touch stay in the L2s /
+//     the Infinity Cache instead of 180 MB per 16,384-bit launch streaming through them (round 5: 203.9 -> 199.2 ms per launch).
+//     A workgroup that finds its XCC's 128 slots taken (never observed; it would take four times the resident workgroups)
+//     falls back to the private slot BRP_PARK_SLOTS + blockIdx.x behind them;
+//   * or PRIVATE (park_owner == null): slot = blockIdx.x, 64 KB per workgroup of the launch (the round-4 layout).
+// Round 5 DERIVED the slot from the hardware id registers read once at the start ("this kernel fits one workgroup per CU, so the
+// physical CU is a collision-free index").  That is wrong whenever the queue is preempted mid-kernel (compute wave save / restore):
+// the workgroups resume on whatever CU the dispatcher gives them (HIP's own __smid(): "the results vary over time"), a resumed
+// workgroup keeps the slot of the CU it STARTED on, and the next workgroup dispatched to that CU derives the same slot -- two live
+// accumulators in one slot.  On the MI355X boxes of this pool such a preemption happens every ~30 s of sustained load; it corrupted
+// the parked halves of 200-260 rows of one launch each time (profiles/r06_park_collision.txt).  Ownership is
+// now a fact recorded in memory, not an inference from where a wave happens to run.
 #define BRP_PARK_SLOTS 1024
+#define BRP_SLOTS_PER_XCC 128
 #ifndef BRP_MAC_PRIO
 #define BRP_MAC_PRIO 1       /* wave priority during the multiply-accumulate (0 / 1 / 3: 214.2 / 211.8 / 212.0 ms per 16,384-bit launch) */
 #endif
@@ -57,6 +68,7 @@
 #endif
 #define BRP_HALF_TILES (EP_GROUPS - 1)                                                   /* 15 tiles per half: group 15 shares group 14's */
 #define BRP_LDS_DOUBLES(R) (2 * FHE_TW_ENTRIES + 2 * BRP_HALF_TILES * GROUP_TILE_DOUBLES + ((R) == 3 ? 6 * FHE_N : 0))   /* R = 3: 159,488 B */
+#define BRP_LDS_EXTRA_DOUBLES 2                                                          /* + the claimed parking slot, broadcast to the eight wavefronts */
 #define BRP_PARK_WORDS_PER_HALF (BRP_RESIDENT_HI ? 8 * EP_THREADS * 2 : 16 * EP_THREADS * 2)   /* per half and iteration: 32 KB (lo[] only) or 64 KB */
 
 __device__ __forceinline__ int brp_opaque_tid()
@@ -68,7 +80,7 @@ __device__ __forceinline__ int brp_opaque_tid()
 
 // One unit = 2R ciphertexts starting at inst0, one 512-thread workgroup.
 template <int K1, int LEVELS, int BASE_LOG, int R>
-__device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, double *lds_all, const uint64_t inst0, const unsigned unit_index)
+__device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, double *lds_all, unsigned *slot_word, const uint64_t inst0, const unsigned unit_index)
 {
     static_assert(K1 == 5, "the column split {0,1} / {2,3} / shared 4 is written for k + 1 = 5");
     static_assert(R * K1 < EP_GROUPS, "a half needs at least one idle lane group");
@@ -133,17 +145,29 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
         }
     }
     const __amdgpu_buffer_rsrc_t park_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.park, 0, (int)A.park_bytes, 0x00020000);
-#if BRP_PARK_BY_CU
-    unsigned hw_xcc, hw_id;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw_xcc));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
-    const unsigned park_slot = ((hw_xcc & 7u) << 7) | ((hw_id >> 8) & 0x7Fu);       // XCC[2:0] | SE_ID[2:0] SH_ID CU_ID[3:0] (HW_ID bits 14..8)
-    const unsigned park_wg = (park_slot * 2u + (unsigned)hh) * (unsigned)(BRP_PARK_WORDS_PER_HALF * 8);      // wave-uniform
-#else
-    const unsigned park_wg = (unit_index * 2u + (unsigned)hh) * (unsigned)(BRP_PARK_WORDS_PER_HALF * 8);       // wave-uniform
-#endif
+    // ---- parking slot: claimed (see the top of this file) or private ----------------------------------------------------------------
+    if (A.park_owner && tid == 0) {
+        unsigned hw_xcc, hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw_xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        const unsigned base = (hw_xcc & 7u) * BRP_SLOTS_PER_XCC, hint = (hw_id >> 8) & (BRP_SLOTS_PER_XCC - 1);
+        unsigned got = BRP_PARK_SLOTS + unit_index;                   // private slot behind the shared ones: only if the XCC's 128 are all owned
+        for (unsigned i = 0; i < BRP_SLOTS_PER_XCC; ++i) {
+            const unsigned sidx = base + ((hint + i) & (BRP_SLOTS_PER_XCC - 1));
+            unsigned expected = 0;
+            // relaxed: the previous owner released the slot only after its last parking access was acknowledged (below), and this
+            // workgroup's first parking store is issued after the barrier that publishes `got`
+            if (__hip_atomic_compare_exchange_strong(A.park_owner + sidx, &expected, unit_index + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                got = sidx;
+                break;
+            }
+        }
+        *slot_word = got;
+    }
 #define BRP_PARK_SLOT(a) ((unsigned)(a) * (EP_THREADS * 16))
-    __syncthreads();   // tables visible
+    __syncthreads();   // tables and the claimed slot visible
+    const unsigned park_slot = A.park_owner ? (unsigned)__builtin_amdgcn_readfirstlane((int)*slot_word) : unit_index;
+    const unsigned park_wg = (park_slot * 2u + (unsigned)hh) * (unsigned)(BRP_PARK_WORDS_PER_HALF * 8);       // wave-uniform
 
     constexpr unsigned GGSW_BYTES = LEVELS * K1 * K1 * FHE_H * 16;
     const __amdgpu_buffer_rsrc_t bsk_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2 *>(A.ggsw), 0, (int)(A.iters * GGSW_BYTES), 0x00020000);
@@ -537,6 +561,14 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
         for (int i = 0; i < EP_NPH; ++i) A.stamps[((size_t)blockIdx.x * 8 + (tid >> 6)) * EP_NPH + i] = ph_cyc[i];
 #endif
 
+    // ---- the claimed slot goes back: only after every wavefront's parking stores (the last iteration's are dead, but in flight) have
+    //      been acknowledged, so that the next owner's stores cannot be overtaken by them ----------------------------------------
+    if (A.park_owner) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0 && park_slot < BRP_PARK_SLOTS) __hip_atomic_store(A.park_owner + park_slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
     // ---- sample extract coefficient 0 ---------------------------------------------------------------
     {
         const int te = brp_opaque_tid() & 255;
@@ -567,13 +599,14 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
 template <int K1, int LEVELS, int BASE_LOG, int R, int R2>
 __global__ __launch_bounds__(BRP_THREADS, 1) void blind_rotate_pair_kernel(const ExtProdArgs A)
 {
-    __shared__ __attribute__((aligned(16))) double lds_all[BRP_LDS_DOUBLES(R)];
-    static_assert(BRP_LDS_DOUBLES(R) * 8 <= 163840, "one workgroup must fit the 160 KB of a CU");
+    __shared__ __attribute__((aligned(16))) double lds_all[BRP_LDS_DOUBLES(R) + BRP_LDS_EXTRA_DOUBLES];
+    static_assert((BRP_LDS_DOUBLES(R) + BRP_LDS_EXTRA_DOUBLES) * 8 <= 163840, "one workgroup must fit the 160 KB of a CU");
+    unsigned *slot_word = reinterpret_cast<unsigned *>(lds_all + BRP_LDS_DOUBLES(R));
     if constexpr (R2 > 0) {
         if (blockIdx.x >= A.units_main) {       // scalar branch
-            blind_rotate_pair_unit<K1, LEVELS, BASE_LOG, R2>(A, lds_all, (uint64_t)A.units_main * (2 * R) + (uint64_t)(blockIdx.x - A.units_main) * (2 * R2), blockIdx.x);
+            blind_rotate_pair_unit<K1, LEVELS, BASE_LOG, R2>(A, lds_all, slot_word, (uint64_t)A.units_main * (2 * R) + (uint64_t)(blockIdx.x - A.units_main) * (2 * R2), blockIdx.x);
             return;
         }
     }
-    blind_rotate_pair_unit<K1, LEVELS, BASE_LOG, R>(A, lds_all, (uint64_t)blockIdx.x * (2 * R), blockIdx.x);
+    blind_rotate_pair_unit<K1, LEVELS, BASE_LOG, R>(A, lds_all, slot_word, (uint64_t)blockIdx.x * (2 * R), blockIdx.x);
 }

@@ -64,6 +64,7 @@ struct ExtProdArgs {
     const uint64_t *glwe_in;    // VP: non-null: the accumulator starts from this GLWE [instance][K1][512] (root of the CMUX tree)
     uint64_t *park;             // kern_blindrot16.h: accumulator parking space, 64 KB per workgroup
     uint64_t park_bytes;        //   its size (< 2^31: one raw buffer)
+    uint32_t *park_owner;       // kern_blindrot_pair.h: owner words of the shared parking slots (0 = free), or null: one private slot per workgroup
     uint32_t units_main;        // kern_blindrot16.h: workgroups below this index carry R ciphertexts, the others R2
 #ifdef EP_STAMPS
     unsigned long long *stamps; // developer build: per-wave cycles per phase [grid][4 waves][EP_NPH]

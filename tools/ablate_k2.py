@@ -27,10 +27,10 @@ VARIANTS = {
     "nobar_skew80": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=80"], "nobar_skew160": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=160"],
  "nopeel": ["-DBRP_ABL_NOPEEL"], "noload": ["-DBR16_ABL_NOLOAD"], "nopark": ["-DBR16_ABL_NOPARK"],
     "nostores_noload": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NODSTORE", "-DBR16_ABL_NOLOAD"],
-    "all6": ["-DK2_PAIR_TAIL4=0"], "parkwg": ["-DBRP_PARK_BY_CU=0"],
+    "all6": ["-DK2_PAIR_TAIL4=0"], "parkwg": [],     # parkwg: the product build with fheaes_k2_set_parking(ctx, 0) (one private slot per workgroup), see RUNTIME
     "pc_1_2": ["-DBR16_PARK_AUX_ST=1"], "pc_2_2": ["-DBR16_PARK_AUX_ST=2"], "pc_3_2": ["-DBR16_PARK_AUX_ST=3"], "pc_17_2": ["-DBR16_PARK_AUX_ST=17"],
-    "pc_0_0": ["-DBR16_PARK_AUX_LD=0"], "pc_0_1": ["-DBR16_PARK_AUX_LD=1"], "pc_0_3": ["-DBR16_PARK_AUX_LD=3"], "pc_0_16": ["-DBR16_PARK_AUX_LD=16"], "pc_0_18": ["-DBR16_PARK_AUX_LD=18"], "parkcu": ["-DBRP_PARK_BY_CU=1"], "parkcu_ld0": ["-DBRP_PARK_BY_CU=1", "-DBR16_PARK_AUX_LD=0"],
-    "parkcu_ld0_st16": ["-DBRP_PARK_BY_CU=1", "-DBR16_PARK_AUX_LD=0", "-DBR16_PARK_AUX_ST=16"], "fewcmul": ["-DBRP_ABL_FEWCMUL"],
+    "pc_0_0": ["-DBR16_PARK_AUX_LD=0"], "pc_0_1": ["-DBR16_PARK_AUX_LD=1"], "pc_0_3": ["-DBR16_PARK_AUX_LD=3"], "pc_0_16": ["-DBR16_PARK_AUX_LD=16"], "pc_0_18": ["-DBR16_PARK_AUX_LD=18"], "park_ld0": ["-DBR16_PARK_AUX_LD=0"],
+    "park_ld0_st16": ["-DBR16_PARK_AUX_LD=0", "-DBR16_PARK_AUX_ST=16"], "fewcmul": ["-DBRP_ABL_FEWCMUL"],
     # ---- round 4: parking ----
     "nohome": ["-DBR16_W3_LDS_HOME=0"],                                   # wavefront 3 parks like the others (idle lanes still skip)
     "r3park": ["-DBR16_W3_LDS_HOME=0", "-DBR16_PARK_OWNERS_ONLY=0"],      # round-3 behaviour: every lane parks
@@ -104,6 +104,8 @@ VARIANTS = {
 
 
 RUNS = 4
+# variants that are a runtime setting of the context, not a build
+RUNTIME = {"parkwg": lambda lib, h: lib.fheaes_k2_set_parking(h, 0)}
 
 
 def main():
@@ -133,6 +135,8 @@ def main():
         cp = p.c_struct()
         assert lib.fheaes_create(ctypes.byref(cp), 0, ctypes.byref(h)) == 0
         assert lib.fheaes_upload_keys(h, keys.ksk.ctypes.data, keys.bsk.ctypes.data, keys.pfpksk.ctypes.data, 0) == 0
+        if name in RUNTIME:
+            assert RUNTIME[name](lib, h) == 0
         d_in = torch.from_numpy(small.view(np.int64)).cuda()
         d_out = torch.empty((M, p.big1), dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()

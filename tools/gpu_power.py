@@ -88,6 +88,25 @@ class Sampler:
         }
 
 
+_once = None
+
+
+def read_once(device=0):
+    """one reading: socket power, shader clock and the temperature sensors the library exposes (edge, junction, memory), for log lines"""
+    global _once
+    if _once is None:
+        _once = Sampler(device=device)
+    s = _once
+    if not s.lib:
+        return {}
+    out = {"w": s._power(), "sclk": s._sclk()}
+    for name, sensor in (("edge", 0), ("junction", 1), ("mem", 2)):
+        t = ctypes.c_int64(0)
+        if s.lib.rsmi_dev_temp_metric_get(s.dev, sensor, 0, ctypes.byref(t)) == 0:      # RSMI_TEMP_CURRENT, millidegrees
+            out[name + "_c"] = t.value / 1000.0
+    return out
+
+
 def fmt(s):
     def f(v, u, d=0):
         return ("%.*f %s" % (d, v, u)) if v is not None else "n/a"
