@@ -35,6 +35,8 @@ IV = 0xF0F1F2F3F4F5F6F7F8F9FAFBFCFDFEFF      # SP 800-38A CTR initial counter bl
 KEY = 0x2B7E151628AED2A6ABF7158809CF4F3C
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8.0 TB/s spec
 F64_VALU_PEAK_TFLOPS = 78.6                   # = half of the 157.3 TF fp32 vector peak of that guide
+I8_MFMA_PEAK_TOPS = 5000.0                    # that guide: I8 MFMA = 2x BF16 per clock, BF16 ~2.5 PF dense -> ~5 POP/s dense (2 ops per MAC)
+I8_MFMA_POWER_CAPPED_TOPS = 3900.0            # a bare v_mfma_i32_16x16x64_i8 loop under this socket's 1,400 W cap: 1.95e15 MAC/s (profiles/r04_ubench_energy.txt)
 
 
 def ext_product_flops(p) -> float:
@@ -484,6 +486,46 @@ def main():
             except Exception:
                 pass
         stage_ms = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items()}
+
+        # ---- the second kernel of a step: K3, private functional packing key switch on the int8 matrix cores (7 % of a step) ----
+        # out[m][z][o] -= sum_{i,l} digit_l(in[m][i]) KEY[z][i][l][o]: an exact integer matrix product mod 2^64 of M x Q by Q x (k+1)^2 N
+        # (Q = (kN+1) x pfks_level) sliced into 15 int8 products per u64 product (kern_keyswitch.h); its HBM view: the key fragments
+        # once per launch + digit planes + the output
+        pf = prof["pfpks"]
+        pf_l = max(1, pf["launches"])
+        pf_ms = pf["ms"] / pf_l
+        pf_bits = pf["units"] / pf_l
+        k1_ = p.k + 1
+        pf_q = p.big1 * p.pfks_level
+        pf_cols = k1_ * k1_ * p.polynomial_size
+        pf_mac = pf_bits * pf_q * pf_cols * 15.0
+        pf_tops = 2.0 * pf_mac / (pf_ms * 1e-3) / 1e12 if pf_ms > 0 else 0.0
+        pf_ksteps = -(-pf_q // 64)
+        pf_bytes = (pf_ksteps * 64 * (-(-pf_cols // 16) * 16) * 8                      # balanced key bytes, fragment order (635.7 MB at PARAM_OPT)
+                    + pf_bits * pf_ksteps * 64 * 2                                     # the two digit planes
+                    + pf_bits * p.big1 * 8 + pf_bits * pf_cols * 8)                    # LWE words in, GGSW rows out
+        roofline_k3 = {
+            "kernel": "digits_kernel<12,3,2> + keyswitch_mfma_lds_kernel<2> (private functional packing key switch, K3)",
+            "bound": "mfma", "achieved": pf_tops, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": pf_tops / I8_MFMA_PEAK_TOPS,
+            "frac_of_power_capped_mfma_loop": pf_tops / I8_MFMA_POWER_CAPPED_TOPS,
+            "avg_launch_ms": pf_ms, "bits_per_launch": pf_bits, "int8_mac_per_launch": pf_mac, "int8_products_per_u64_product": 15,
+            "traffic": None,
+            "hbm": {"bound": "hbm", "achieved": pf_bytes / (pf_ms * 1e-3) / 1e9 if pf_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (pf_bytes / (pf_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if pf_ms > 0 else 0.0, "algorithmic_bytes_per_launch": pf_bytes},
+            "note": "share of a step: %.1f %%; dense int8 peak = 2 x the BF16 MFMA rate (MI355X_MICROARCH.md); the chip holds 0.78 of it in a bare "
+                    "MFMA loop under the 1,400 W cap" % (100.0 * pf["ms"] / max(1e-9, sum(v["ms"] for v in prof.values()))),
+        }
+        for pmc in sorted((ROOT / "profiles").glob("*pmc_pfpks*.json")):
+            try:
+                d = json.loads(pmc.read_text())
+                if d.get("engine_src_sha256") == _build.engine_source_hash() and d.get("bits_per_launch") == pf_bits and d.get("params") == p.name:
+                    roofline_k3["traffic"] = d.get("hbm_bytes_per_launch")
+                    roofline_k3["traffic_source"] = pmc.name
+                    for k_ in ("mfma_busy_frac", "lds_bank_conflict_frac", "effective_clock_ghz", "l2_hit_rate"):
+                        if k_ in d:
+                            roofline_k3[k_] = d[k_]
+            except Exception:
+                pass
         # the kernel THIS context launches for such a batch (fheaes_k2_context_plan: after the occupancy fallbacks), not an assumption
         k2p = eng.k2_plan(int(bits_per_launch))
         line = {
@@ -537,6 +579,7 @@ def main():
                         "algorithmic_bytes_per_launch": algo_bytes,
                         "note": "one pass over the 342.5 MB Fourier BSK per launch + per-bit I/O (5,360 B in, 16,392 B out)"},
             },
+            "roofline_k3": roofline_k3,
             "setup_s": {"keygen": round(keygen_s, 2), ("key_upload_h2d" if world == 1 else "key_broadcast_" + ("rccl" if args.backend == "nccl" else args.backend)): round(bcast_s, 3),
                         "key_bytes_moved": key_bytes_moved, "key_expand_and_convert_on_gpu": round(expand_s, 3),
                         "aes_key_expansion": None if keyexp_s is None else round(keyexp_s, 3)},

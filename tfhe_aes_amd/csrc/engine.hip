@@ -441,8 +441,16 @@ int launch_keyswitch(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *ou
     a.afrag = af; a.bfrag = c->ksk_frag; a.ksteps = c->ks_ksteps; a.coltiles = c->ks_coltiles;
     a.in = in; a.in_stride = c->big1; a.body_index = (int32_t)c->big; a.body_col = c->n; a.ncols = c->n + 1;
     a.out = out; a.out_stride = c->n + 1; a.out_z_stride = 0; a.m = m;
+#ifndef KS1_LDS
+#define KS1_LDS 0                      /* 1: K1 through the LDS-tiled kernel too (round 6 experiment) */
+#endif
+#if KS1_LDS
+    dim3 grid((c->ks_coltiles + KSL_COL_TILES - 1) / KSL_COL_TILES, (unsigned)((m + 16 * KSL_CT_TILES - 1) / (16 * KSL_CT_TILES)), 1);
+    hipLaunchKernelGGL((keyswitch_mfma_lds_kernel<1>), grid, dim3(KSL_THREADS), 0, c->stream, a);
+#else
     dim3 grid((c->ks_coltiles + 3) / 4, (unsigned)((m + KS_CT_TILE - 1) / KS_CT_TILE), 1);
     hipLaunchKernelGGL((keyswitch_mfma_kernel<1>), grid, dim3(KS_THREADS), 0, c->stream, a);
+#endif
     HIP_TRY(c, hipGetLastError());
     return FHEAES_OK;
 }

@@ -191,8 +191,11 @@ __global__ __launch_bounds__(KS_THREADS, 2) void keyswitch_mfma_kernel(const Key
 // ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPR staging; the
 // fragments are already stored in MFMA lane order, so the LDS image is the HBM image) and read by every wave
 // that needs them: 48 KB per 480 MFMAs.  Double buffered: the loads of step ks+1 fly during the MFMAs of ks.
-#define KSL_THREADS 512
-#define KSL_CT_TILES 8          /* 128 ciphertexts */
+#ifndef KSL_CT_TILES
+#define KSL_CT_TILES 8          /* 8: 128 ciphertexts per 512-thread workgroup, one workgroup per CU (96 KB of LDS); 4: 64 ciphertexts per 256-thread
+                                   workgroup, two independent workgroups per CU (80 KB each: no common barrier, the key fragments come in twice) */
+#endif
+#define KSL_THREADS (64 * KSL_CT_TILES)
 #define KSL_COL_TILES 4         /* 64 columns */
 
 template <int PLANES>
@@ -217,9 +220,10 @@ __global__ __launch_bounds__(KSL_THREADS, 2) void keyswitch_mfma_lds_kernel(cons
 
     // fragment f of a K step: f < A_FRAGS: digits (ct tile f / PLANES, plane f % PLANES); else key (col tile, byte plane)
     auto issue = [&](uint32_t ks, int buf) {
+        constexpr int WAVES = KSL_THREADS / 64;
 #pragma unroll
-        for (int i = 0; i < (FRAGS + 7) / 8; ++i) {
-            const int f = wave + 8 * i;                        // wave-uniform
+        for (int i = 0; i < (FRAGS + WAVES - 1) / WAVES; ++i) {
+            const int f = wave + WAVES * i;                    // wave-uniform
             if (f < FRAGS) {
                 const int8_t *src;
                 if (f < A_FRAGS) {

@@ -20,6 +20,9 @@ from tfhe_aes_amd.client import Client  # noqa: E402
 VARIANTS = {
     "base": [],
     "nolds": ["-DKS_LDS=0"],          # the one-wave-one-tile form (operands straight from L2)
+    "k1lds": ["-DKS1_LDS=1"],         # round 6: K1 through the LDS-tiled kernel
+    "ct4_k1lds": ["-DKSL_CT_TILES=4", "-DKS1_LDS=1"],
+    "ct4": ["-DKSL_CT_TILES=4"],      # round 6: 256-thread workgroups of 64 ciphertexts, two per CU (no common barrier between the two)
 }
 
 

@@ -20,8 +20,11 @@ launches = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 p = PARAM_OPT
 c = Client(1, 1, 2, params=p, seed=0xAE50001)
 keys = c.server_keys()
-E = _native.Engine(p)
+E = _native.Engine(p, allow_dev_build=True)
 E.upload_keys(keys.ksk, keys.bsk, keys.pfpksk)
+import os  # noqa: E402
+if os.environ.get("K2_PARKING") == "private":          # one private parking slot per workgroup instead of the claimed pool
+    E.k2_set_parking(False)
 rng = np.random.default_rng(0)
 small = torch.from_numpy(rng.integers(0, 1 << 64, (M, p.n + 1), dtype=np.uint64).view(np.int64)).cuda()
 out = torch.empty((M, p.big1), dtype=torch.int64, device="cuda")
