@@ -442,7 +442,7 @@ int launch_keyswitch(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *ou
     a.in = in; a.in_stride = c->big1; a.body_index = (int32_t)c->big; a.body_col = c->n; a.ncols = c->n + 1;
     a.out = out; a.out_stride = c->n + 1; a.out_z_stride = 0; a.m = m;
 #ifndef KS1_LDS
-#define KS1_LDS 0                      /* 1: K1 through the LDS-tiled kernel too (round 6 experiment) */
+#define KS1_LDS 1                      /* 1 (round 6: 1.87 -> 1.48 ms per 16,384-bit launch, same words): K1 through the LDS-tiled kernel too; 0: one wave = one tile, operands from L2 */
 #endif
 #if KS1_LDS
     dim3 grid((c->ks_coltiles + KSL_COL_TILES - 1) / KSL_COL_TILES, (unsigned)((m + 16 * KSL_CT_TILES - 1) / (16 * KSL_CT_TILES)), 1);

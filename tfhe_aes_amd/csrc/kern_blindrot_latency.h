@@ -31,6 +31,15 @@
 #ifndef BL_L2_PREFETCH
 #define BL_L2_PREFETCH 1
 #endif
+#ifndef BL_ROWS_AHEAD
+#define BL_ROWS_AHEAD 3      /* levels of GGSW rows in flight during the multiply-accumulate.  1 (rounds 2-5): the first level requested at the top of the
+                                iteration (its registers live through the rotation and the transform), level k+1 requested while level k is used -- the
+                                stamps of round 6 (profiles/r06_latency_stamps.txt) show the phase waiting a whole (hot-spotted: every workgroup walks
+                                the same rows at the same time) L2 round trip per level: 9.7 k of an iteration's 25.6 k cycles for 300 fused
+                                multiply-adds per thread.  3: nothing is held across the transform; when its registers are free the rows of levels
+                                0, 1 and 2 are requested at once (three register sets), level k+3 refills the set level k has just left, row by row:
+                                one exposed round trip per iteration instead of five */
+#endif
 
 template <int K1, int LEVELS, int BASE_LOG>
 __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(const ExtProdArgs A)
@@ -45,7 +54,7 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
     uint64_t *accs = reinterpret_cast<uint64_t *>(lds + ROWS * GROUP_TILE_DOUBLES);            // [K1][512]
 
     const int tid = threadIdx.x;
-    const int g = tid >> 4, b = tid & 15;
+    const int g = tid >> 4;
     const bool transform = g < ROWS;                  // group (l_idx, p): row index g = k*K1 + p, k = 0 is the least significant level
     const bool owner = g < K1;                        // output polynomial g is inverse-transformed by this group
     const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: what depends on it stays in SGPRs / scalar branches
@@ -83,15 +92,19 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
     unsigned pf_sink = 0;
     // One level of GGSW rows in flight per thread: (Fourier point tid mod 256) x (this half's share of the columns).  The rows of
     // the first level of iteration it+1 do not depend on data: they are requested at the end of iteration it (and here for it = 0).
-    double2 bq[K1][CA];
+#if BL_ROWS_AHEAD != 3
+    double2 bq[1][K1][CA];
+#endif
     const unsigned col_bytes = half_b ? (unsigned)CA * (FHE_H * 16) : 0u;      // wave-uniform
+#if BL_ROWS_AHEAD != 3
     auto load_row = [&](unsigned gb, unsigned mp_, int k, int p, double2 (&dst)[CA]) {
 #pragma unroll
         for (int c = 0; c < CA; ++c)
             if (c < CB || !half_b) dst[c] = ep_key_load(bsk_rsrc, mp_ * 16u, gb + row_bytes(k, p) + col_bytes + (unsigned)c * (FHE_H * 16));
     };
 #pragma unroll
-    for (int p = 0; p < K1; ++p) load_row(0u, (unsigned)(tid & 255), 0, p, bq[p]);
+    for (int p = 0; p < K1; ++p) load_row(0u, (unsigned)(tid & 255), 0, p, bq[0][p]);
+#endif
     for (uint32_t it = 0; it < A.iters; ++it) {
         const int t = mod_switch_1024(a_next);
         a_next = lwe[it + 1];                          // one iteration ahead (the last one reads the body: unused)
@@ -167,6 +180,60 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
                 *reinterpret_cast<double2 *>(tile + 2 * (bq_ + 16 * k2)) = v;
             }
         }
+#if BL_ROWS_AHEAD == 3
+        // ---- 2. multiply-accumulate: all 512 threads, one Fourier point and a share of the columns each.  The two halves of the
+        //      workgroup own 3 and 2 columns (k + 1 = 5): each half runs its OWN copy of the phase with the column count a compile-time
+        //      constant and its own row registers (with one shared copy and a per-column `if (half_b)` the compiler sinks the conditional
+        //      column's products of all 25 rows of the unrolled chain into one block and keeps every row alive until then: 179 spills) ----
+        double fr[CA], fi[CA];
+#pragma unroll
+        for (int c = 0; c < CA; ++c) { fr[c] = 0.0; fi[c] = 0.0; }
+        auto mac_phase = [&](auto nc) {
+            constexpr int NC = decltype(nc)::value;
+            auto load_row_n = [&](unsigned gb, int k, int p, double2 (&dst)[NC]) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    dst[c] = ep_key_load(bsk_rsrc, (unsigned)mp * 16u, gb + row_bytes(k, p) + col_bytes + (unsigned)c * (FHE_H * 16));
+            };
+            // one chain level: rows p = 0..K1-1 out of `cur`; after row p is consumed its registers take row p of level k + BL_ROWS_AHEAD
+            auto mac_level = [&](const int k, double2 (&cur)[K1][NC]) {
+                const double *dl = lds + (size_t)k * K1 * GROUP_TILE_DOUBLES + 2 * mp;      // digits of chain level k
+                double2 dn = *reinterpret_cast<const double2 *>(dl);
+#pragma unroll
+                for (int p = 0; p < K1; ++p) {
+                    double2 bv[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) bv[c] = cur[p][c];
+                    if (k + BL_ROWS_AHEAD < LEVELS) load_row_n(g_bytes, k + BL_ROWS_AHEAD, p, cur[p]);      // the same row, BL_ROWS_AHEAD levels on
+                    const double2 d = dn;
+                    if (p + 1 < K1) dn = *reinterpret_cast<const double2 *>(dl + (p + 1) * GROUP_TILE_DOUBLES);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        fr[c] = __builtin_fma(d.x, bv[c].x, fr[c]);
+                        fr[c] = __builtin_fma(-d.y, bv[c].y, fr[c]);
+                        fi[c] = __builtin_fma(d.x, bv[c].y, fi[c]);
+                        fi[c] = __builtin_fma(d.y, bv[c].x, fi[c]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // the transform's registers are free: the rows of the first three levels are requested at once (they land behind the barrier)
+            double2 rows[3][K1][NC];
+            __builtin_amdgcn_sched_barrier(0);         // not earlier: during the transform there is no register to spare
+#pragma unroll
+            for (int k = 0; k < 3 && k < LEVELS; ++k)
+#pragma unroll
+                for (int p = 0; p < K1; ++p) load_row_n(g_bytes, k, p, rows[k][p]);
+            __builtin_amdgcn_sched_barrier(0);
+            EP_STAMP(3);
+            wg_barrier_lds_only();                     // digits visible; the key loads stay in flight
+            EP_STAMP(4);
+#pragma unroll
+            for (int k = 0; k < LEVELS; ++k) mac_level(k, rows[k % 3]);
+        };
+        if (half_b) mac_phase(std::integral_constant<int, CB>{}); else mac_phase(std::integral_constant<int, CA>{});
+#else
         EP_STAMP(3);
         wg_barrier_lds_only();                         // digits visible; the key loads stay in flight
         EP_STAMP(4);
@@ -182,8 +249,8 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
             for (int p = 0; p < K1; ++p) {
                 double2 bv[CA];
 #pragma unroll
-                for (int c = 0; c < CA; ++c) bv[c] = bq[p][c];
-                if (k + 1 < LEVELS) load_row(g_bytes, (unsigned)mp, k + 1, p, bq[p]);      // the same row of the next level, one level ahead
+                for (int c = 0; c < CA; ++c) bv[c] = bq[0][p][c];
+                if (k + 1 < LEVELS) load_row(g_bytes, (unsigned)mp, k + 1, p, bq[0][p]);      // the same row of the next level, one level ahead
                 const double2 d = dn;
                 if (p + 1 < K1) dn = *reinterpret_cast<const double2 *>(dl + (p + 1) * GROUP_TILE_DOUBLES);
                 __builtin_amdgcn_sched_barrier(0);
@@ -199,6 +266,7 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#endif
 #if BL_L2_PREFETCH
 #pragma unroll
         for (int i = 0; i < 8; ++i) pf_sink ^= pf[i];
@@ -213,11 +281,13 @@ __global__ __launch_bounds__(BL_THREADS, 2) void blind_rotate_latency_kernel(con
                 *reinterpret_cast<double2 *>(lds + ((half_b ? CA : 0) + c) * GROUP_TILE_DOUBLES + 2 * mp) = v;
             }
         }
+#if BL_ROWS_AHEAD != 3
         // the first level's rows of the NEXT iteration: every row register is free again
         if (it + 1 < A.iters) {
 #pragma unroll
-            for (int p = 0; p < K1; ++p) load_row(g_next, (unsigned)mp, 0, p, bq[p]);
+            for (int p = 0; p < K1; ++p) load_row(g_next, (unsigned)mp, 0, p, bq[0][p]);
         }
+#endif
         EP_STAMP(7);
         wg_barrier_lds_only();
         EP_STAMP(8);

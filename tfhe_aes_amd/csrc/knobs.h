@@ -14,7 +14,7 @@
     /* equivalent-result tuning knobs (defaults in the headers are the measured best) */ \
     X(BR16_MAC_PRIO) X(BR16_EARLY) X(BR16_XPOSE_IN_TWIDDLE) X(BR16_STAGE_AT_END) X(BR16_HEAD) X(BR16_LATE_IN_PASS2) \
     X(BR16_READ_IN_PASS2) X(BR16_STORE_IN_PASS2) X(BR16_PARK_AUX_ST) X(BR16_PARK_AUX_LD) X(BR16_PARK_OWNERS_ONLY) X(BR16_W3_LDS_HOME) X(BR16_RESIDENT_HI) X(BR16_W1_LATE) X(BR16_MAC_TAIL) \
-    X(BL_L2_PREFETCH) X(EP_EARLY_LOAD) X(EP_MAC_PRIO) X(EP_ROT_CHUNK) X(EP_PREFETCH) X(EP_KEY_AUX) X(EP_FENCE_MASK) X(EP_MIN_WAVES) \
+    X(BL_L2_PREFETCH) X(BL_ROWS_AHEAD) X(EP_EARLY_LOAD) X(EP_MAC_PRIO) X(EP_ROT_CHUNK) X(EP_PREFETCH) X(EP_KEY_AUX) X(EP_FENCE_MASK) X(EP_MIN_WAVES) \
     X(EP_LATE_BARRIER) X(FFT_XPOSE_PRIO) X(FFT_CHUNK) X(FFT_CHUNK_BARRIERS) X(FHE_TORUS_CONV_OLD) \
     X(LATENCY_BATCH_BITS) X(PBS_BALANCE) X(PBS_SMALL_R2) X(KS_LDS) X(KSL_SPLIT4) X(KSL_CT_TILES) X(KS1_LDS) X(K2_PAIR) X(K2_PAIR_MIN_BITS) X(K2_PAIR_TAIL4) X(BRP_EARLY) X(BRP_TAIL) X(BRP_RESIDENT_HI) X(BRP_W1_LATE) X(BRP_MAC_PRIO) X(BRP_CHUNK)
 
@@ -24,7 +24,7 @@
     defined(ABL_NO_MAC) || defined(ABL_MAC_NOLDS) || defined(BR16_PAD_DOUBLES) || \
     defined(BR16_MAC_PRIO) || defined(BR16_EARLY) || defined(BR16_XPOSE_IN_TWIDDLE) || defined(BR16_STAGE_AT_END) || defined(BR16_HEAD) || \
     defined(BR16_LATE_IN_PASS2) || defined(BR16_READ_IN_PASS2) || defined(BR16_STORE_IN_PASS2) || defined(BR16_PARK_AUX_ST) || \
-    defined(BR16_PARK_AUX_LD) || defined(BR16_PARK_OWNERS_ONLY) || defined(BR16_W3_LDS_HOME) || defined(BR16_RESIDENT_HI) || defined(BR16_W1_LATE) || defined(BR16_MAC_TAIL) || defined(BL_L2_PREFETCH) || \
+    defined(BR16_PARK_AUX_LD) || defined(BR16_PARK_OWNERS_ONLY) || defined(BR16_W3_LDS_HOME) || defined(BR16_RESIDENT_HI) || defined(BR16_W1_LATE) || defined(BR16_MAC_TAIL) || defined(BL_L2_PREFETCH) || defined(BL_ROWS_AHEAD) || \
     defined(EP_EARLY_LOAD) || defined(EP_MAC_PRIO) || \
     defined(EP_ROT_CHUNK) || defined(EP_PREFETCH) || defined(EP_KEY_AUX) || defined(EP_FENCE_MASK) || defined(EP_MIN_WAVES) || \
     defined(EP_LATE_BARRIER) || defined(FFT_XPOSE_PRIO) || defined(FFT_CHUNK) || defined(FFT_CHUNK_BARRIERS) || defined(FHE_TORUS_CONV_OLD) || \

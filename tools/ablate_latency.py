@@ -13,7 +13,7 @@ import torch  # noqa: E402,F401
 from tfhe_aes_amd import PARAM_OPT, _build, _native  # noqa: E402
 from tfhe_aes_amd.client import Client  # noqa: E402
 
-VARIANTS = {"base": [],  "samekey": ["-DBL_ABL_SAMEKEY"], "nopf": ["-DBL_L2_PREFETCH=0"], "nopf_samekey": ["-DBL_L2_PREFETCH=0", "-DBL_ABL_SAMEKEY"], "pf2": ["-DBL_PREFETCH=2"], "pf3": ["-DBL_PREFETCH=3"], "pf4": ["-DBL_PREFETCH=4"], "off": ["-DLATENCY_BATCH_BITS=0ull"]}
+VARIANTS = {"base": [], "ahead1": ["-DBL_ROWS_AHEAD=1"],  "samekey": ["-DBL_ABL_SAMEKEY"], "nopf": ["-DBL_L2_PREFETCH=0"], "nopf_samekey": ["-DBL_L2_PREFETCH=0", "-DBL_ABL_SAMEKEY"], "pf2": ["-DBL_PREFETCH=2"], "pf3": ["-DBL_PREFETCH=3"], "pf4": ["-DBL_PREFETCH=4"], "off": ["-DLATENCY_BATCH_BITS=0ull"]}
 names = sys.argv[1].split(",") if len(sys.argv) > 1 else list(VARIANTS)
 out = Path("gpurun_out/abl"); out.mkdir(parents=True, exist_ok=True)
 p = PARAM_OPT

@@ -32,8 +32,21 @@ cd $R
 python3 tools/summarize_pmc.py $O/pmc "blind_rotate_pair_kernel<5, 5" profiles/${ROUND}_pmc_blind_rotate 16384 --cus 256 --dyncount $O/k2_dyncount.txt \
         --flops-per-ct-iteration 609280 --cts-per-wg 5.8182 --waves-per-wg 8 --algorithmic-bytes 698912768 > $O/pmc_summary.txt
 cp profiles/${ROUND}_pmc_blind_rotate.json $O/
+# the second kernel of a step (K3, packing key switch): its own counter passes and summary (bench.py attaches them to roofline_k3)
+cd /tmp
+pmc3() { name=$1; shift; timeout -k 10 150 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_k3/$name -- python3 $R/tools/run_k3.py 16384 3 > $O/pmc_k3_$name.log 2>&1; }
+pmc3 fetch FETCH_SIZE
+pmc3 write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+pmc3 sq SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS
+pmc3 grbm GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum
+pmc3 mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_I8 SQ_INSTS_MFMA
+cd $R
+python3 tools/summarize_pmc_k3.py $O/pmc_k3 profiles/${ROUND}_pmc_pfpks 16384 > $O/pmc_k3_summary.txt
+cp profiles/${ROUND}_pmc_pfpks.json $O/
 cd /tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 tail -1 $O/bench.json | cut -c1-300
+# the driver's exact command (every block of every step verified; exit code 1 on a wrong one)
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_style.json 2> $O/bench_driver_style.err && echo "driver-style bench: all verified" || echo "driver-style bench FAILED (see bench_driver_style.err)"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/prof.log 2>&1
 echo done
