@@ -71,10 +71,13 @@ def test_k3_pfpks(which, m, request):
     assert np.array_equal(out, kit.oracle.pfpks(x))
 
 
-def test_k4_forward_fourier(toy):
-    E = toy.engine()
+@pytest.mark.parametrize("which", ["toy", "opt"])
+def test_k4_forward_fourier(which, request):
+    # the kernel does not depend on the parameter set at N = 512 (one polynomial per 16-lane group); both engines anyway, every word
+    # against the oracle, up to 300 polynomials (19 workgroups, ragged last one)
+    E = request.getfixturevalue(which).engine()
     rng = np.random.default_rng(4)
-    for polys in (1, 15, 16, 17, 130):
+    for polys in (1, 15, 16, 17, 130, 300):
         x = rng.integers(0, 1 << 64, (polys, 512), dtype=np.uint64)
         out = np.zeros((polys, 256, 2), dtype=np.float64)
         E.forward_fourier_batch(x, out, polys)
