@@ -50,6 +50,9 @@
 //     the Infinity Cache instead of 180 MB per 16,384-bit launch streaming through them (round 5: 203.9 -> 199.2 ms per launch).
 //     A workgroup that finds its XCC's 128 slots taken (never observed; it would take four times the resident workgroups)
 //     falls back to the private slot BRP_PARK_SLOTS + blockIdx.x behind them;
+//     A compute unit's L1 cannot serve a stale line of a re-used slot: a lane reads back only what it has itself stored since it
+//     owns the slot (stores update or invalidate the line), and a workgroup streams ~600 KB of key rows per iteration through the
+//     32 KB L1, so nothing an earlier owner left there survives even one iteration (27 us), let alone a hand-over;
 //   * or PRIVATE (park_owner == null): slot = blockIdx.x, 64 KB per workgroup of the launch (the round-4 layout).
 // Round 5 DERIVED the slot from the hardware id registers read once at the start ("this kernel fits one workgroup per CU, so the
 // physical CU is a collision-free index").  That is wrong whenever the queue is preempted mid-kernel (compute wave save / restore):
