@@ -295,20 +295,33 @@ def test_chained_encrypt_steps_then_decrypt_shard_every_block(opt, opt_server):
 
 
 def test_random_key_round_trips_param_opt(opt, opt_server):
-    """main.rs:120-141 at the reference's parameter set on the GPU: random (key, plaintext) pairs, key expansion -> encrypt -> decrypt,
-    both directions checked against FIPS-197 arithmetic.  Three keys, four blocks each (the evaluation keys stay: they do not depend
-    on the AES key)."""
-    c = opt.client
+    """main.rs:120-141 at the reference's parameter set on the GPU: ten random (AES key, plaintext) pairs, one block each, key expansion ->
+    encrypt -> decrypt, both directions checked against FIPS-197 arithmetic (`test_verify`, client.rs:147-175) -- eight of them under
+    the session's evaluation keys, and, as the reference draws a NEW client per pair, two under freshly generated FHE keys (a fresh
+    `Client` with a random seed, a fresh engine context, the keys uploaded in their seeded form)."""
+    from tfhe_aes_amd import _native
+    from tfhe_aes_amd.client import Client
+
     rng = np.random.default_rng(0x120141)
-    for _ in range(3):
-        key = int.from_bytes(rng.bytes(16), "big")
-        pts = [int.from_bytes(rng.bytes(16), "big") for _ in range(4)]
-        rk = opt_server.aes_key_expansion(c.encrypt_u128(key))
+
+    def round_trip(c, srv, key, pt):
+        rk = srv.aes_key_expansion(c.encrypt_u128(key))
         assert np.array_equal(c.decrypt_bytes(rk), np.array(aes_clear.expand_key(key), dtype=np.uint8))
-        st = np.stack([c.encrypt_u128(v) for v in pts])
-        enc = opt_server.aes_encrypt(rk, st.copy())
-        for i, v in enumerate(pts):
-            assert c.decrypt_u128(enc[i]) == aes_clear.aes128_encrypt_block(key, v)
-        dec = opt_server.aes_decrypt(rk, enc.copy())
-        for i, v in enumerate(pts):
-            assert c.decrypt_u128(dec[i]) == v
+        st = c.encrypt_u128(pt)[None]
+        enc = srv.aes_encrypt(rk, st.copy())
+        assert c.decrypt_u128(enc[0]) == aes_clear.aes128_encrypt_block(key, pt)
+        dec = srv.aes_decrypt(rk, enc.copy())
+        assert c.decrypt_u128(dec[0]) == pt
+
+    for _ in range(8):
+        round_trip(opt.client, opt_server, int.from_bytes(rng.bytes(16), "big"), int.from_bytes(rng.bytes(16), "big"))
+    for _ in range(2):
+        key, pt = int.from_bytes(rng.bytes(16), "big"), int.from_bytes(rng.bytes(16), "big")
+        c2 = Client(1, pt, key, params=opt.params, seed=int.from_bytes(rng.bytes(8), "big"))
+        eng = _native.Engine(opt.params, device=0)
+        try:
+            seeded = c2.server_keys().compress()
+            eng.upload_keys_seeded(seeded.mask_key, seeded.ksk_body, seeded.bsk_body, seeded.pfpksk_body)
+            round_trip(c2, Server(None, device=0, engine=eng, clone_from=None) if False else _FreshServer(eng, opt.params), key, pt)
+        finally:
+            eng.close()

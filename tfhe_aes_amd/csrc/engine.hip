@@ -26,7 +26,7 @@
 #include "kern_keyswitch.h"
 #include "kern_linear.h"
 
-#define FHEAES_VERSION_STR "fheaes-mi355x 0.2 (gfx950)" FHEAES_BUILD_KIND      /* " dev" when built with developer knobs (knobs.h) */
+#define FHEAES_VERSION_STR "fheaes-mi355x 0.3 (gfx950)" FHEAES_BUILD_KIND      /* " dev" when built with developer knobs (knobs.h) */
 #define MAX_CHUNK_BITS 32768ull
 #define MAX_WOPBS_BITS 16u            /* widest radix input of many_wopbs_without_padding (LUT of 2^16 entries per output bit) */
 
