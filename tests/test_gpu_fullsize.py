@@ -298,8 +298,7 @@ def test_random_key_round_trips_param_opt(opt, opt_server):
     """main.rs:120-141 at the reference's parameter set on the GPU: ten random (AES key, plaintext) pairs, one block each, key expansion ->
     encrypt -> decrypt, both directions checked against FIPS-197 arithmetic (`test_verify`, client.rs:147-175) -- eight of them under
     the session's evaluation keys, and, as the reference draws a NEW client per pair, two under freshly generated FHE keys (a fresh
-    `Client` with a random seed, a fresh engine context, the keys uploaded in their seeded form)."""
-    from tfhe_aes_amd import _native
+    `Client`, a fresh `Server` with its own engine context and upload)."""
     from tfhe_aes_amd.client import Client
 
     rng = np.random.default_rng(0x120141)
@@ -318,10 +317,8 @@ def test_random_key_round_trips_param_opt(opt, opt_server):
     for _ in range(2):
         key, pt = int.from_bytes(rng.bytes(16), "big"), int.from_bytes(rng.bytes(16), "big")
         c2 = Client(1, pt, key, params=opt.params, seed=int.from_bytes(rng.bytes(8), "big"))
-        eng = _native.Engine(opt.params, device=0)
+        srv2 = Server(c2.server_keys(), device=0)            # Server::new(public_key, sks, wopbs_key): its own context, its own upload
         try:
-            seeded = c2.server_keys().compress()
-            eng.upload_keys_seeded(seeded.mask_key, seeded.ksk_body, seeded.bsk_body, seeded.pfpksk_body)
-            round_trip(c2, Server(None, device=0, engine=eng, clone_from=None) if False else _FreshServer(eng, opt.params), key, pt)
+            round_trip(c2, srv2, key, pt)
         finally:
-            eng.close()
+            srv2.engine.close()
