@@ -14,8 +14,9 @@
 //   groups 0..K1-1          inverse transform of output polynomial c, accumulate into LDS.
 // Round 2: the chain of an iteration was dominated by exposed round trips, not by arithmetic -- 25 dependent GGSW
 // row fetches with two rows in flight (~600 cycles each), and one LDS table read in flight per twiddle multiply.  Now
-//   * the K1 rows of the first level of the multiply-accumulate are requested at the TOP of the iteration (they do not
-//     depend on data) and land during the rotation / decomposition / transform; afterwards one level (K1 rows) stays in flight;
+//   * (rounds 2-5) the K1 rows of the first level of the multiply-accumulate were requested at the TOP of the iteration and one level
+//     stayed in flight afterwards; round 6 (BL_ROWS_AHEAD = 3, below): nothing is held across the transform, three levels of rows
+//     are requested at once behind it -- one exposed L2 round trip per iteration instead of one per level;
 //   * the multiply-accumulate is split by output column over all 512 threads (3 + 2 columns), halving its length and
 //     the registers a row occupies; key rows come through raw buffer loads with scalar row offsets;
 //   * the transform's table entries are read as one batch, a whole pass ahead of their use (fft_dev.h);
@@ -34,7 +35,7 @@
 #ifndef BL_ROWS_AHEAD
 #define BL_ROWS_AHEAD 3      /* levels of GGSW rows in flight during the multiply-accumulate.  1 (rounds 2-5): the first level requested at the top of the
                                 iteration (its registers live through the rotation and the transform), level k+1 requested while level k is used -- the
-                                stamps of round 6 (profiles/r06_latency_stamps.txt) show the phase waiting a whole (hot-spotted: every workgroup walks
+                                stamps of round 6 (profiles/r06_latency_stamps_before.txt) show the phase waiting a whole (hot-spotted: every workgroup walks
                                 the same rows at the same time) L2 round trip per level: 9.7 k of an iteration's 25.6 k cycles for 300 fused
                                 multiply-adds per thread.  3: nothing is held across the transform; when its registers are free the rows of levels
                                 0, 1 and 2 are requested at once (three register sets), level k+3 refills the set level k has just left, row by row:
