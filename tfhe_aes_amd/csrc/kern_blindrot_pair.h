@@ -69,6 +69,14 @@
 #ifndef BRP_CHUNK
 #define BRP_CHUNK 1          /* butterflies issued together in this kernel's transforms (fft_dev.h dft16; 1 / 2 / 4 / 8: 211.5 / 214.4 / 214.2 / 223.4 ms) */
 #endif
+#ifndef BRP_SKIP_IDLE_WAVES
+#define BRP_SKIP_IDLE_WAVES 1 /* four-ciphertext units (R = 2): the last wavefront of either half (lane groups 12-15) owns no polynomial -- it is needed for
+                                the multiply-accumulate (every thread owns a Fourier point) and for the products exchange, but its rotation, transforms
+                                and conversion work on nothing.  1: those two wavefronts run their OWN iteration body (the same barriers, their key
+                                rows, the multiply-accumulate, the exchange; a wave-uniform branch at the top of the iteration) -- one generation of
+                                eleven in a 16,384-bit launch, one of three in a 4,096-bit one.  The six-ciphertext body is not touched (its one idle
+                                group shares a wavefront with three busy ones) */
+#endif
 #define BRP_HALF_TILES (EP_GROUPS - 1)                                                   /* 15 tiles per half: group 15 shares group 14's */
 #define BRP_LDS_DOUBLES(R) (2 * FHE_TW_ENTRIES + 2 * BRP_HALF_TILES * GROUP_TILE_DOUBLES + ((R) == 3 ? 6 * FHE_N : 0))   /* R = 3: 159,488 B */
 #define BRP_LDS_EXTRA_DOUBLES 2                                                          /* + the claimed parking slot, broadcast to the eight wavefronts */
@@ -103,6 +111,8 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
     const int r_own = owner ? g / K1 : R - 1;
     const int p_own = owner ? g % K1 : K1 - 1;
     const bool home_wave = HOME && __builtin_amdgcn_readfirstlane(tq0) >= 16 * HOME_G0;
+    // wave-uniform: this wavefront's four lane groups own no polynomial (R = 2: groups 12..15 of either half)
+    const bool idle_wave = BRP_SKIP_IDLE_WAVES && R * K1 <= 12 && __builtin_amdgcn_readfirstlane(tq0) >= 16 * 12;
     double *ldsh = lds + hh * (BRP_HALF_TILES * GROUP_TILE_DOUBLES);                      // this half's tiles (scalar)
     double *ldso = lds + (1 - hh) * (BRP_HALF_TILES * GROUP_TILE_DOUBLES);                // the other half's
     auto tile_of = [&](const int tq) -> double * {
@@ -202,7 +212,7 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
         }
 #endif
     };
-    {
+    if (!idle_wave) {
         const int tq = brp_opaque_tid() & 255;
 #pragma unroll
         for (int a = 0; a < 16; ++a) stage_park(a, tq);
@@ -216,6 +226,74 @@ __device__ __forceinline__ void blind_rotate_pair_unit(const ExtProdArgs &A, dou
         a_next = lwe[it + 1];
         const unsigned g_bytes = it * GGSW_BYTES;
 
+        if (idle_wave) {
+            // ---- a wavefront without polynomials (BRP_SKIP_IDLE_WAVES): the barriers of the others, its key rows, its share of the
+            //      multiply-accumulate and of the products exchange -- nothing else.  Same sums in the same order as level_body below ----
+            const int tq = brp_opaque_tid() & 255;
+            double g2r[RT][2], g2i[RT][2], g4r[R], g4i[R];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) { g2r[r][0] = g2r[r][1] = 0.0; g2i[r][0] = g2i[r][1] = 0.0; }
+#pragma unroll
+            for (int r = 0; r < R; ++r) { g4r[r] = 0.0; g4i[r] = 0.0; }
+#pragma unroll 1
+            for (int l = LEVELS - 1; l >= 0; --l) {
+                const unsigned gl_bytes = g_bytes + (unsigned)l * (K1 * K1 * FHE_H * 16) + col_bytes;   // scalar
+                double2 bm[K1][3];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int p = q / 3, j = q % 3;
+                    const unsigned off = j < 2 ? gl_bytes + (unsigned)(p * K1 + j) * (FHE_H * 16)
+                                               : gl_bytes - col_bytes + (unsigned)(p * K1 + K1 - 1) * (FHE_H * 16);
+                    bm[p][j] = ep_key_load(bsk_rsrc, (unsigned)tq * 16u, off);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (l != LEVELS - 1) wg_barrier_lds_only();      // the others: "done reading the previous level's digits"
+                wg_barrier_lds_only();                            // the digits of this level are visible
+                const double *own = ldsh + 2 * tq, *oth = ldso + 2 * tq;
+#pragma unroll
+                for (int p = 0; p < K1; ++p) {
+                    double2 d[RT];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) d[r] = *reinterpret_cast<const double2 *>((r < R ? own : oth) + ((r % R) * K1 + p) * GROUP_TILE_DOUBLES);
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            g2r[r][j] = __builtin_fma(d[r].x, bm[p][j].x, g2r[r][j]);
+                            g2r[r][j] = __builtin_fma(-d[r].y, bm[p][j].y, g2r[r][j]);
+                            g2i[r][j] = __builtin_fma(d[r].x, bm[p][j].y, g2i[r][j]);
+                            g2i[r][j] = __builtin_fma(d[r].y, bm[p][j].x, g2i[r][j]);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        g4r[r] = __builtin_fma(d[r].x, bm[p][2].x, g4r[r]);
+                        g4r[r] = __builtin_fma(-d[r].y, bm[p][2].y, g4r[r]);
+                        g4i[r] = __builtin_fma(d[r].x, bm[p][2].y, g4i[r]);
+                        g4i[r] = __builtin_fma(d[r].y, bm[p][2].x, g4i[r]);
+                    }
+                }
+            }
+            wg_barrier_lds_only();                                // everybody is done reading the last level's digits
+            {
+                double *own = ldsh + 2 * tq, *oth = ldso + 2 * tq;
+                const int c0 = 2 * hh;
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        double2 v; v.x = g2r[r][j]; v.y = g2i[r][j];
+                        *reinterpret_cast<double2 *>((r < R ? own : oth) + ((r % R) * K1 + c0 + j) * GROUP_TILE_DOUBLES) = v;
+                    }
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    double2 v; v.x = g4r[r]; v.y = g4i[r];
+                    *reinterpret_cast<double2 *>(own + (r * K1 + K1 - 1) * GROUP_TILE_DOUBLES) = v;
+                }
+            }
+            wg_barrier_lds_only();                                // products in place
+            continue;
+        }
         // ---- d = acc * X^t - acc; first (least significant) digit ---------------------------------------------------------------
         uint32_t st_lo[16], st_hi[16];
         static_assert(BASE_LOG == 8 && LEVELS == 5, "the signed-byte decomposition state is written for five levels of eight bits");

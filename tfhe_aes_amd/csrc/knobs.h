@@ -16,7 +16,7 @@
     X(BR16_READ_IN_PASS2) X(BR16_STORE_IN_PASS2) X(BR16_PARK_AUX_ST) X(BR16_PARK_AUX_LD) X(BR16_PARK_OWNERS_ONLY) X(BR16_W3_LDS_HOME) X(BR16_RESIDENT_HI) X(BR16_W1_LATE) X(BR16_MAC_TAIL) \
     X(BL_L2_PREFETCH) X(BL_ROWS_AHEAD) X(EP_EARLY_LOAD) X(EP_MAC_PRIO) X(EP_ROT_CHUNK) X(EP_PREFETCH) X(EP_KEY_AUX) X(EP_FENCE_MASK) X(EP_MIN_WAVES) \
     X(EP_LATE_BARRIER) X(FFT_XPOSE_PRIO) X(FFT_CHUNK) X(FFT_CHUNK_BARRIERS) X(FHE_TORUS_CONV_OLD) \
-    X(LATENCY_BATCH_BITS) X(PBS_BALANCE) X(PBS_SMALL_R2) X(KS_LDS) X(KSL_SPLIT4) X(KSL_CT_TILES) X(KS1_LDS) X(K2_PAIR) X(K2_PAIR_MIN_BITS) X(K2_PAIR_TAIL4) X(BRP_EARLY) X(BRP_TAIL) X(BRP_RESIDENT_HI) X(BRP_W1_LATE) X(BRP_MAC_PRIO) X(BRP_CHUNK)
+    X(LATENCY_BATCH_BITS) X(PBS_BALANCE) X(PBS_SMALL_R2) X(KS_LDS) X(KSL_SPLIT4) X(KSL_CT_TILES) X(KS1_LDS) X(K2_PAIR) X(K2_PAIR_MIN_BITS) X(K2_PAIR_TAIL4) X(BRP_EARLY) X(BRP_TAIL) X(BRP_RESIDENT_HI) X(BRP_W1_LATE) X(BRP_MAC_PRIO) X(BRP_CHUNK) X(BRP_SKIP_IDLE_WAVES)
 
 #ifndef FHEAES_DEV_BUILD
 #if defined(EP_STAMPS) || defined(BR16_ABL_SAMEKEY) || defined(BR16_ABL_NOLOAD) || defined(BR16_ABL_NOMAC) || defined(BR16_ABL_NOFFT) || \
@@ -29,7 +29,7 @@
     defined(EP_ROT_CHUNK) || defined(EP_PREFETCH) || defined(EP_KEY_AUX) || defined(EP_FENCE_MASK) || defined(EP_MIN_WAVES) || \
     defined(EP_LATE_BARRIER) || defined(FFT_XPOSE_PRIO) || defined(FFT_CHUNK) || defined(FFT_CHUNK_BARRIERS) || defined(FHE_TORUS_CONV_OLD) || \
     defined(LATENCY_BATCH_BITS) || defined(PBS_BALANCE) || defined(PBS_SMALL_R2) || defined(KS_LDS) || defined(KSL_SPLIT4) || defined(KSL_CT_TILES) || defined(KS1_LDS) || defined(K2_PAIR) || defined(K2_PAIR_MIN_BITS) || defined(K2_PAIR_TAIL4) || \
-    defined(BRP_EARLY) || defined(BRP_TAIL) || defined(BRP_RESIDENT_HI) || defined(BRP_W1_LATE) || defined(BRP_MAC_PRIO) || defined(BRP_CHUNK)
+    defined(BRP_EARLY) || defined(BRP_TAIL) || defined(BRP_RESIDENT_HI) || defined(BRP_W1_LATE) || defined(BRP_MAC_PRIO) || defined(BRP_CHUNK) || defined(BRP_SKIP_IDLE_WAVES)
 #error "a developer knob of the kernels is defined on the command line: product builds take no knobs (add -DFHEAES_DEV_BUILD for a developer build; see csrc/knobs.h)"
 #endif
 #define FHEAES_BUILD_KIND ""

@@ -27,7 +27,7 @@ VARIANTS = {
     "nobar_skew80": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=80"], "nobar_skew160": ["-DBRP_ABL_NOBAR", "-DBRP_ABL_SKEW=160"],
  "nopeel": ["-DBRP_ABL_NOPEEL"], "noload": ["-DBR16_ABL_NOLOAD"], "nopark": ["-DBR16_ABL_NOPARK"],
     "nostores_noload": ["-DBRP_ABL_NOXSTORE", "-DBRP_ABL_NODSTORE", "-DBR16_ABL_NOLOAD"],
-    "all6": ["-DK2_PAIR_TAIL4=0"], "parkwg": [],     # parkwg: the product build with fheaes_k2_set_parking(ctx, 0) (one private slot per workgroup), see RUNTIME
+    "all6": ["-DK2_PAIR_TAIL4=0"], "noskip": ["-DBRP_SKIP_IDLE_WAVES=0"], "parkwg": [],     # parkwg: the product build with fheaes_k2_set_parking(ctx, 0) (one private slot per workgroup), see RUNTIME
     "pc_1_2": ["-DBR16_PARK_AUX_ST=1"], "pc_2_2": ["-DBR16_PARK_AUX_ST=2"], "pc_3_2": ["-DBR16_PARK_AUX_ST=3"], "pc_17_2": ["-DBR16_PARK_AUX_ST=17"],
     "pc_0_0": ["-DBR16_PARK_AUX_LD=0"], "pc_0_1": ["-DBR16_PARK_AUX_LD=1"], "pc_0_3": ["-DBR16_PARK_AUX_LD=3"], "pc_0_16": ["-DBR16_PARK_AUX_LD=16"], "pc_0_18": ["-DBR16_PARK_AUX_LD=18"], "park_ld0": ["-DBR16_PARK_AUX_LD=0"],
     "park_ld0_st16": ["-DBR16_PARK_AUX_LD=0", "-DBR16_PARK_AUX_ST=16"], "fewcmul": ["-DBRP_ABL_FEWCMUL"],
