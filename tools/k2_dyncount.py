@@ -58,7 +58,9 @@ for h, n in size.items():
         tot[parent_of[h]] += n
 outer = [h for h in tot if h not in parent_of and tot[h] > 1500]
 outer.sort(key=lambda h: next(b[0] for b in blocks if b[2] == h))
-H = outer[unit]
+# round 6: the four-ciphertext body's iteration loop is no longer one annotated loop (its idle wavefronts run their own body behind a
+# wave-uniform branch, and LLVM unswitches it): the six-ciphertext body is then the only large annotated loop -- take the last one
+H = outer[min(unit, len(outer) - 1)]
 level_loops = [h for h, p in parent_of.items() if p == H and size[h] > 300]
 
 
