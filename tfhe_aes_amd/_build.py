@@ -18,8 +18,11 @@ CSRC = PKG / "csrc"
 ENGINE_SO = PKG / "libfheaes.so"
 CLIENT_SO = PKG / "libfheaes_client.so"
 
-ENGINE_SOURCES = [CSRC / "engine.hip"]
+# Two translation units (csrc/ks_launch.h says why): engine.hip = everything but the key-switching kernels, compiled with LLVM's
+# post-register-allocation scheduler OFF; keyswitch_tu.hip = K1 / K3 / the key-byte conversion, default schedulers.
+ENGINE_SOURCES = [CSRC / "engine.hip", CSRC / "keyswitch_tu.hip"]
 ENGINE_HEADERS = sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.hpp")) + [ROOT / "include" / "fheaes.h"]
+BUILD_DIR = PKG / "build"
 
 
 def _stale(target: Path, deps) -> bool:
@@ -43,23 +46,49 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def engine_flags():
+def _common_flags():
     # -ffp-contract=off: the canonical arithmetic only fuses where the source says fma()
     # -disable-machine-licm: the transforms' ~50 lane-independent twiddle constants are 64-bit literals moved into SGPR pairs;
     #   hoisted out of the 669-iteration loop they would all be live at once (12 SGPRs spilled to a VGPR, 20 B/lane of scratch in
     #   the blind rotation); left where they are used they cost a scalar move each, on the otherwise idle scalar unit
     return [
-        "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
         "-ffp-contract=off", "-fno-fast-math", "-mllvm", "-disable-machine-licm", "-Wall",
         "-Wno-unused-function", "-I", str(ROOT / "include"), "-I", str(CSRC),
     ]
 
 
+# round 6: the post-RA scheduler re-orders what the blind-rotation kernels place by hand; without it a 16,384-bit launch takes
+# 197.3 instead of 200.5 ms (same box, same words; profiles/r06_k2_ablations.txt).  The key switch wants it ON (15.9 vs 16.6 ms).
+NO_POST_RA_SCHED = ["-mllvm", "-enable-post-misched=false"]
+
+
+def unit_flags(unit: str):
+    """compile flags of one unit of the product library: "engine" (engine.hip) or "keyswitch" (keyswitch_tu.hip)"""
+    if unit == "engine":
+        return _common_flags() + ["-DFHEAES_SPLIT_KS"] + NO_POST_RA_SCHED
+    if unit == "keyswitch":
+        return _common_flags() + ["-DFHEAES_SPLIT_KS"]
+    raise ValueError(unit)
+
+
+def engine_flags(unit: str = "engine"):
+    """flags of a SINGLE-UNIT developer build (`hipcc <these> -o lib.so csrc/engine.hip`, as tools/ablate_*.py do it): engine.hip alone
+    is then a complete library, every kernel in it compiled under the scheduler setting of the product unit named (`unit="keyswitch"`
+    for experiments on K1 / K3)"""
+    return _common_flags() + ["-shared"] + (NO_POST_RA_SCHED if unit == "engine" else [])
+
+
 def build_engine(force: bool = False, extra=()) -> Path:
     # this file is a dependency too: it holds the compile flags (a library built before a flag changed must not be reused)
     if force or _stale(ENGINE_SO, ENGINE_SOURCES + ENGINE_HEADERS + [Path(__file__)]):
-        cmd = [hipcc_path()] + engine_flags() + list(extra) + ["-o", str(ENGINE_SO)] + [str(s) for s in ENGINE_SOURCES]
-        _run(cmd)
+        BUILD_DIR.mkdir(exist_ok=True)
+        objs = []
+        for src, unit in zip(ENGINE_SOURCES, ("engine", "keyswitch")):
+            obj = BUILD_DIR / (src.stem + ".o")
+            _run([hipcc_path()] + unit_flags(unit) + list(extra) + ["-c", "-o", str(obj), str(src)])
+            objs.append(str(obj))
+        _run([hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(ENGINE_SO)] + objs)
     return ENGINE_SO
 
 
@@ -81,7 +110,8 @@ def engine_source_hash() -> str:
         h.update(Path(f).name.encode())
         h.update(Path(f).read_bytes())
     # ... and the compile flags (without the machine-specific include paths): the same sources under other flags are other kernels
-    h.update(" ".join(x for x in engine_flags() if not x.startswith("/")).encode())
+    for unit in ("engine", "keyswitch"):
+        h.update(" ".join(x for x in unit_flags(unit) if not x.startswith("/")).encode())
     return h.hexdigest()
 
 

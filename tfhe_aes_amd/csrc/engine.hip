@@ -23,7 +23,7 @@
 #include "kern_blindrot_latency.h"
 #include "kern_blindrot16.h"
 #include "kern_blindrot_pair.h"
-#include "kern_keyswitch.h"
+#include "ks_launch.h"                 // kern_keyswitch.h: the kernels themselves, or (two-unit product build) their argument block + launch functions
 #include "kern_linear.h"
 
 #define FHEAES_VERSION_STR "fheaes-mi355x 0.3 (gfx950)" FHEAES_BUILD_KIND      /* " dev" when built with developer knobs (knobs.h) */
@@ -436,7 +436,7 @@ int launch_keyswitch(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *ou
     TRY(ensure(c, c->ws_digits, ct_tiles16 * c->ks_ksteps * 1024));
     int8_t *af = (int8_t *)c->ws_digits.p;
     const uint64_t threads = ct_tiles16 * c->ks_ksteps * 64;
-    hipLaunchKernelGGL((digits_kernel<2, 6, 1>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, in, (uint64_t)c->big1, c->big, m, c->ks_ksteps, af);
+    ks_launch_digits_k1(dim3((unsigned)((threads + 255) / 256)), c->stream, in, (uint64_t)c->big1, c->big, m, c->ks_ksteps, af);
     KeyswitchArgs a{};
     a.afrag = af; a.bfrag = c->ksk_frag; a.ksteps = c->ks_ksteps; a.coltiles = c->ks_coltiles;
     a.in = in; a.in_stride = c->big1; a.body_index = (int32_t)c->big; a.body_col = c->n; a.ncols = c->n + 1;
@@ -446,10 +446,10 @@ int launch_keyswitch(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *ou
 #endif
 #if KS1_LDS
     dim3 grid((c->ks_coltiles + KSL_COL_TILES - 1) / KSL_COL_TILES, (unsigned)((m + 16 * KSL_CT_TILES - 1) / (16 * KSL_CT_TILES)), 1);
-    hipLaunchKernelGGL((keyswitch_mfma_lds_kernel<1>), grid, dim3(KSL_THREADS), 0, c->stream, a);
+    ks_launch_mfma_lds(1, grid, c->stream, a);
 #else
     dim3 grid((c->ks_coltiles + 3) / 4, (unsigned)((m + KS_CT_TILE - 1) / KS_CT_TILE), 1);
-    hipLaunchKernelGGL((keyswitch_mfma_kernel<1>), grid, dim3(KS_THREADS), 0, c->stream, a);
+    ks_launch_mfma(1, grid, c->stream, a);
 #endif
     HIP_TRY(c, hipGetLastError());
     return FHEAES_OK;
@@ -465,7 +465,7 @@ int launch_pfpks(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *out, u
     TRY(ensure(c, c->ws_digits, ct_tiles16 * c->pf_ksteps * 2 * 1024));
     int8_t *af = (int8_t *)c->ws_digits.p;
     const uint64_t threads = ct_tiles16 * c->pf_ksteps * 64;
-    hipLaunchKernelGGL((digits_kernel<12, 3, 2>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream, in, (uint64_t)c->big1, c->big1, m, c->pf_ksteps, af);
+    ks_launch_digits_k3(dim3((unsigned)((threads + 255) / 256)), c->stream, in, (uint64_t)c->big1, c->big1, m, c->pf_ksteps, af);
     KeyswitchArgs a{};
     a.afrag = af; a.bfrag = c->pfpksk_frag; a.ksteps = c->pf_ksteps; a.coltiles = c->pf_coltiles;
     a.in = in; a.in_stride = c->big1; a.body_index = -1; a.body_col = 0; a.ncols = gsz;
@@ -475,10 +475,10 @@ int launch_pfpks(fheaes_ctx *c, const uint64_t *in, uint64_t m, uint64_t *out, u
 #endif
 #if KS_LDS
     dim3 grid((c->pf_coltiles + KSL_COL_TILES - 1) / KSL_COL_TILES, (unsigned)((m + 16 * KSL_CT_TILES - 1) / (16 * KSL_CT_TILES)), c->k1);
-    hipLaunchKernelGGL((keyswitch_mfma_lds_kernel<2>), grid, dim3(KSL_THREADS), 0, c->stream, a);
+    ks_launch_mfma_lds(2, grid, c->stream, a);
 #else
     dim3 grid((c->pf_coltiles + 3) / 4, (unsigned)((m + KS_CT_TILE - 1) / KS_CT_TILE), c->k1);
-    hipLaunchKernelGGL((keyswitch_mfma_kernel<2>), grid, dim3(KS_THREADS), 0, c->stream, a);
+    ks_launch_mfma(2, grid, c->stream, a);
 #endif
     HIP_TRY(c, hipGetLastError());
     return FHEAES_OK;
@@ -1035,15 +1035,14 @@ static int upload_keys_impl(fheaes_ctx *c, const uint64_t *ksk, const uint64_t *
     {
         const uint64_t *d = staged(0, ksk, kw);
         const uint64_t threads = (uint64_t)c->ks_ksteps * c->ks_coltiles * 64;
-        hipLaunchKernelGGL(keybytes_kernel, dim3((unsigned)((threads + 255) / 256), 1), dim3(256), 0, c->stream, d, (uint64_t)0, rows1, ncol1,
-                           c->ks_ksteps, c->ks_coltiles, c->ksk_frag);
+        ks_launch_keybytes(dim3((unsigned)((threads + 255) / 256), 1), c->stream, d, (uint64_t)0, rows1, ncol1, c->ks_ksteps, c->ks_coltiles, c->ksk_frag);
         if (tmp) (void)hipStreamSynchronize(c->stream);
     }
     {
         const uint64_t *d = staged(2, pfpksk, pw);
         const uint64_t threads = (uint64_t)c->pf_ksteps * c->pf_coltiles * 64;
-        hipLaunchKernelGGL(keybytes_kernel, dim3((unsigned)((threads + 255) / 256), c->k1), dim3(256), 0, c->stream, d, (uint64_t)rows3 * ncol3, rows3, ncol3,
-                           c->pf_ksteps, c->pf_coltiles, c->pfpksk_frag);
+        ks_launch_keybytes(dim3((unsigned)((threads + 255) / 256), c->k1), c->stream, d, (uint64_t)rows3 * ncol3, rows3, ncol3, c->pf_ksteps, c->pf_coltiles,
+                           c->pfpksk_frag);
         if (tmp) (void)hipStreamSynchronize(c->stream);
     }
     {

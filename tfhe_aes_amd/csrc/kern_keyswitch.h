@@ -30,6 +30,36 @@
 
 typedef int ks_int4 __attribute__((ext_vector_type(4)));
 
+// With FHEAES_KS_DECLS_ONLY only the constants and the argument block are visible (engine.hip in the two-unit product build, where the
+// kernels of this file are compiled in keyswitch_tu.hip under other scheduler flags: csrc/ks_launch.h).
+struct KeyswitchArgs {
+    const int8_t *afrag;       // [ct tiles][ksteps][PLANES][64][16]
+    const int8_t *bfrag;       // [z][ksteps][coltiles][8][64][16]
+    uint32_t ksteps, coltiles;
+    const uint64_t *in;        // original LWE words (for the body term of K1)
+    uint64_t in_stride;
+    int32_t body_index;        // >= 0: in[m][body_index] is added to column body_col; < 0: none
+    uint32_t body_col;
+    uint32_t ncols;
+    uint64_t *out;             // column o of key z at out[m*out_stride + z*out_z_stride + o]
+    uint64_t out_stride, out_z_stride;
+    uint64_t m;
+};
+
+// ---- LDS-tiled form: 512 threads = 8 waves own a 128-ciphertext x 64-column output tile -------------------
+// The one-wave-one-tile kernel above is bound by the L2 -> CU operand stream (40 KB per 240 MFMAs: measured
+// 36 % of the int8 MFMA rate).  Here the 8 digit fragments and the 32 key fragments of a K step are brought in
+// ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPR staging; the
+// fragments are already stored in MFMA lane order, so the LDS image is the HBM image) and read by every wave
+// that needs them: 48 KB per 480 MFMAs.  Double buffered: the loads of step ks+1 fly during the MFMAs of ks.
+#ifndef KSL_CT_TILES
+#define KSL_CT_TILES 8          /* 8: 128 ciphertexts per 512-thread workgroup, one workgroup per CU (96 KB of LDS); 4: 64 ciphertexts per 256-thread
+                                   workgroup, two independent workgroups per CU (80 KB each: no common barrier, the key fragments come in twice) */
+#endif
+#define KSL_THREADS (64 * KSL_CT_TILES)
+#define KSL_COL_TILES 4         /* 64 columns */
+
+#ifndef FHEAES_KS_DECLS_ONLY
 // ---- key bytes: u64 KEY[z][rows][ncols] -> balanced int8 planes in B-fragment order (run once at upload) ----
 __global__ __launch_bounds__(256) void keybytes_kernel(const uint64_t *key, uint64_t key_z_stride, uint32_t rows, uint32_t ncols,
                                                        uint32_t ksteps, uint32_t coltiles, int8_t *frag)
@@ -112,20 +142,6 @@ __global__ __launch_bounds__(256) void digits_kernel(const uint64_t *in, uint64_
     }
 }
 
-struct KeyswitchArgs {
-    const int8_t *afrag;       // [ct tiles][ksteps][PLANES][64][16]
-    const int8_t *bfrag;       // [z][ksteps][coltiles][8][64][16]
-    uint32_t ksteps, coltiles;
-    const uint64_t *in;        // original LWE words (for the body term of K1)
-    uint64_t in_stride;
-    int32_t body_index;        // >= 0: in[m][body_index] is added to column body_col; < 0: none
-    uint32_t body_col;
-    uint32_t ncols;
-    uint64_t *out;             // column o of key z at out[m*out_stride + z*out_z_stride + o]
-    uint64_t out_stride, out_z_stride;
-    uint64_t m;
-};
-
 template <int PLANES>
 __global__ __launch_bounds__(KS_THREADS, 2) void keyswitch_mfma_kernel(const KeyswitchArgs A)
 {
@@ -184,19 +200,6 @@ __global__ __launch_bounds__(KS_THREADS, 2) void keyswitch_mfma_kernel(const Key
         }
 }
 
-
-// ---- LDS-tiled form: 512 threads = 8 waves own a 128-ciphertext x 64-column output tile -------------------
-// The one-wave-one-tile kernel above is bound by the L2 -> CU operand stream (40 KB per 240 MFMAs: measured
-// 36 % of the int8 MFMA rate).  Here the 8 digit fragments and the 32 key fragments of a K step are brought in
-// ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, no VGPR staging; the
-// fragments are already stored in MFMA lane order, so the LDS image is the HBM image) and read by every wave
-// that needs them: 48 KB per 480 MFMAs.  Double buffered: the loads of step ks+1 fly during the MFMAs of ks.
-#ifndef KSL_CT_TILES
-#define KSL_CT_TILES 8          /* 8: 128 ciphertexts per 512-thread workgroup, one workgroup per CU (96 KB of LDS); 4: 64 ciphertexts per 256-thread
-                                   workgroup, two independent workgroups per CU (80 KB each: no common barrier, the key fragments come in twice) */
-#endif
-#define KSL_THREADS (64 * KSL_CT_TILES)
-#define KSL_COL_TILES 4         /* 64 columns */
 
 template <int PLANES>
 __global__ __launch_bounds__(KSL_THREADS, 2) void keyswitch_mfma_lds_kernel(const KeyswitchArgs A)
@@ -284,3 +287,4 @@ __global__ __launch_bounds__(KSL_THREADS, 2) void keyswitch_mfma_lds_kernel(cons
             A.out[ct * A.out_stride + (uint64_t)z * A.out_z_stride + col] = v;
         }
 }
+#endif  // FHEAES_KS_DECLS_ONLY

@@ -21,8 +21,11 @@ c = Client(1, 1, 2, params=p, seed=0xAE50001)
 keys = c.server_keys()
 x = c.encrypt_bytes(list(range(16)))
 for name in names:
-    so = out / ("libfheaes_lat_%s.so" % name)
-    subprocess.run([_build.hipcc_path()] + _build.engine_flags() + ["-DFHEAES_DEV_BUILD"] + VARIANTS[name] + ["-o", str(so), str(_build.ENGINE_SOURCES[0])], check=True, capture_output=True)
+    if name.startswith("so:"):                          # an already built library
+        so = Path(name[3:])
+    else:
+        so = out / ("libfheaes_lat_%s.so" % name)
+        subprocess.run([_build.hipcc_path()] + _build.engine_flags() + ["-DFHEAES_DEV_BUILD"] + VARIANTS[name] + ["-o", str(so), str(_build.ENGINE_SOURCES[0])], check=True, capture_output=True)
     lib = ctypes.CDLL(str(so))
     for fn, (res, args) in _native.SIGNATURES.items():
         f = getattr(lib, fn); f.restype, f.argtypes = res, args

@@ -15,7 +15,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 # the ISA-count x issue-cost model of the blind-rotation kernel (tools/k2_dyncount.py) for roofline.ceiling_frac
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -mllvm -disable-machine-licm -I $R/include -I $R/tfhe_aes_amd/csrc -S --cuda-device-only \
+# (the product's engine unit: its flags come from tfhe_aes_amd/_build.py -- post-RA scheduler off, key-switching kernels in the other unit)
+hipcc $(python3 -c 'from tfhe_aes_amd import _build; print(" ".join(_build.unit_flags("engine")))') -S --cuda-device-only \
       -o /tmp/engine_final.s $R/tfhe_aes_amd/csrc/engine.hip 2> /dev/null
 python3 $R/tools/k2_dyncount.py /tmp/engine_final.s blind_rotate_pair_kernelILi5ELi5ELi8ELi3ELi2 1 0 | tee $O/k2_dyncount.txt
 # build (if stale) BEFORE anything runs under the profiler: hipcc must not be spawned from a process tree rocprofv3 has GPU-initialised
