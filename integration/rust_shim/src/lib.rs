@@ -63,6 +63,9 @@ extern "C" {
     pub fn fheaes_clone_info(ctx: *mut fheaes_ctx, path: *mut c_int, bytes: *mut u64, seconds: *mut f64) -> c_int;
     pub fn fheaes_noise_level_seen(ctx: *mut fheaes_ctx, max_seen: *mut u32, limit: *mut u32) -> c_int;
     pub fn fheaes_synchronize(ctx: *mut fheaes_ctx) -> c_int;
+    /// where the paired blind rotation parks half of its accumulators: 1 = slots claimed from a shared pool (default), 0 = one private
+    /// slot per workgroup; same words either way (a maintainer only needs it to rule the pool out when chasing a wrong result)
+    pub fn fheaes_k2_set_parking(ctx: *mut fheaes_ctx, claimed: c_int) -> c_int;
     pub fn fheaes_wopbs_batch(ctx: *mut fheaes_ctx, lwe_in: *const u64, n_inputs: u64, bits: u32, luts: *const u64,
                               n_luts: u32, lut_per_input: c_int, lwe_out: *mut u64, memspace: c_int) -> c_int;
     pub fn fheaes_sbox(ctx: *mut fheaes_ctx, bytes: *mut u64, n_bytes: u64, inv: c_int, memspace: c_int) -> c_int;
